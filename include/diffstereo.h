@@ -1,0 +1,143 @@
+/*
+ * diffstereo -- C ABI of the MI355X (gfx950) implementation of diffusion_stereo's
+ * hot path: cost volume -> min-sum diffusion sweeps (red-black checkerboard) ->
+ * energy / label extraction.
+ *
+ * The reference (Helga-Helga/stereo-vision, crate diffusion_stereo) has no FFI or
+ * plugin boundary: `DiffusionGraph` is a plain Rust struct with public fields and
+ * methods that `CrossingOutGraph` and `main` call in-process.  Each entry point
+ * below therefore replaces one public method (or public-field access) of that
+ * struct; the citation names it.  A Rust host links this library from build.rs
+ * and keeps the crate's public functions as thin wrappers.
+ *
+ * Conventions
+ *  - Every function returns DS_OK (0) or a negative DS_ERR_* code.  No C++
+ *    exception and no HIP error crosses the boundary; ds_last_error() gives text.
+ *  - A handle is used by one host thread at a time.  It owns its device memory
+ *    and, unless ds_set_stream() was called, its own HIP stream.
+ *  - Host buffers stay owned by the caller and are only touched during the call.
+ *  - Images are 8-bit, row-major [H][W].  1 <= D <= 256 (the reference reuses its
+ *    256x256 |a-b| table for |d-d'|, diffusion_graph.rs:71-76,137).
+ *  - "phi" arrays at the boundary use the reference layout potentials[i][j][n][d]
+ *    (diffusion_graph.rs:43): row-major [rows][W][4][D], element type float
+ *    (DS_F32) or double (DS_F64); neighbour slot n: 0=left 1=top 2=right 3=bottom
+ *    (utils.rs:29-34).  Entries the reference never touches (d > j, or slot
+ *    without neighbour) read back as 0.
+ *  - A handle may own only the row band [row_begin, row_end) of the image (one
+ *    band per GPU).  It then also stores one halo row above and below; the host
+ *    moves halo rows between neighbouring bands after each colour's half-sweep
+ *    (ds_halo gives the device pointers).
+ */
+#ifndef DIFFSTEREO_H
+#define DIFFSTEREO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ds_handle ds_handle;
+
+enum { DS_F32 = 0, DS_F64 = 1 };
+
+enum {
+    DS_OK = 0,
+    DS_ERR_ARG = -1,    /* invalid argument */
+    DS_ERR_HIP = -2,    /* a HIP runtime call failed (text in ds_last_error) */
+    DS_ERR_STATE = -3,  /* call not valid in the handle's current state */
+    DS_ERR_NOMEM = -4   /* host or device allocation failed */
+};
+
+/* Replaces DiffusionGraph::initialize (diffusion_stereo/src/diffusion_graph.rs:65-88):
+ * copies the images, allocates phi (all zero) on the current HIP device and builds
+ * the cost volume.  lambda = smoothing_term. */
+int ds_create(const uint8_t *left, const uint8_t *right, int H, int W, int D, double lambda,
+              int dtype, ds_handle **out);
+
+/* Same, for the band of image rows [row_begin, row_end) of an H x W image;
+ * left/right are still the full images.  device < 0 keeps the current device. */
+int ds_create_band(const uint8_t *left, const uint8_t *right, int H, int W, int D, double lambda,
+                   int dtype, int row_begin, int row_end, int device, ds_handle **out);
+
+void ds_destroy(ds_handle *h);
+
+/* Text of the last error on this handle (or of the last failed ds_create* when h is NULL). */
+const char *ds_last_error(const ds_handle *h);
+
+/* Run all work of this handle on the given hipStream_t (NULL = the handle's own stream). */
+int ds_set_stream(ds_handle *h, void *hip_stream);
+
+/* Waits until all work queued by this handle has finished. */
+int ds_synchronize(ds_handle *h);
+
+/* Stage 1.  Replaces the implicit data term lookup_table[L[i][j]][R[i][j-d]]
+ * (diffusion_graph.rs:71-76,120-121): materialises cost[d][i][j] = |L[i][j] - R[i][j-d]|
+ * as 8-bit label-major [D][rows][W] (0 where d > j) and repacks it for the sweep.
+ * ds_create* already calls it; calling it again rebuilds. */
+int ds_build_cost(ds_handle *h);
+
+/* Copies the label-major cost volume [D][rows][W] (rows = the handle's band) to the host. */
+int ds_get_cost(ds_handle *h, uint8_t *out);
+
+/* Stage 2.  Replaces n_iters calls of DiffusionGraph::diffusion_act
+ * (diffusion_graph.rs:264-341) under the red-black schedule: all pixels with
+ * (i+j) even, then all with (i+j) odd.  Synchronous at return.  Only valid on a
+ * handle that owns the whole image (bands need the halo exchange between colours:
+ * use ds_sweep). */
+int ds_iterate(ds_handle *h, int n_iters);
+
+/* One colour's half-sweep (diffusion_act_vertexes + diffusion_act_edges,
+ * diffusion_graph.rs:302-341, at every pixel of that colour) over the image rows
+ * [row_begin, row_end), which must lie inside the handle's band.  Asynchronous:
+ * queued on the handle's stream. */
+int ds_sweep(ds_handle *h, int colour, int row_begin, int row_end);
+
+/* Replaces DiffusionGraph::energy (diffusion_graph.rs:502-518) for the handle's
+ * rows: sum of min_d f_t(d) plus, for slots 2 and 3, min_{d,d'} g_tt'(d,d').  The
+ * edge to the row below a band uses the bottom halo.  Band energies add up to the
+ * image's energy.  *max_residual (may be NULL) receives max |f_t(d)| over the band. */
+int ds_energy(ds_handle *h, double *energy, double *max_residual);
+
+/* Stage 3.  mode 1 replaces min_penalty_vertex / build_depth_map
+ * (diffusion_graph.rs:376-390,456-470): argmin_d f_t(d), first minimum wins.
+ * mode 0 takes the same argmin of f_t as it stands after the pixel's vertex step
+ * (diffusion_graph.rs:302-317), i.e. of q_t(d) + sum_n min_d' (lambda|d-d'| + phi_t'n'(d')).
+ * out: [rows][W]. */
+int ds_labels(ds_handle *h, int mode, uint32_t *out);
+
+/* Replace direct access to the public field `potentials` (diffusion_graph.rs:43).
+ * Rows [row_begin, row_end) may include the band's halo rows. */
+int ds_get_phi_rows(ds_handle *h, int row_begin, int row_end, void *out);
+int ds_set_phi_rows(ds_handle *h, int row_begin, int row_end, const void *in);
+/* The handle's own rows (no halo). */
+int ds_get_phi(ds_handle *h, void *out);
+int ds_set_phi(ds_handle *h, const void *in);
+
+/* Halo rows of a band.  side: 0 = top edge of the band, 1 = bottom edge.
+ * which: 0 = the row to send to the neighbouring band after `colour`'s half-sweep
+ * (top: slot-1 messages of the band's first row; bottom: slot-3 messages of its
+ * last row), 1 = where the neighbour's row is received (top: slot-3 messages of the
+ * row above; bottom: slot-1 messages of the row below).  Both are contiguous
+ * device buffers of *bytes bytes with identical internal layout on both sides. */
+int ds_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_t *bytes);
+
+/* Per-launch timing of the sweep kernel with HIP events on the handle's stream.
+ * ds_profile_begin clears the counters and enables timing (at most max_launches
+ * launches are timed); ds_profile_end synchronises, disables timing and reports the
+ * number of timed launches and their total / min / max duration in milliseconds. */
+int ds_profile_begin(ds_handle *h, int max_launches);
+int ds_profile_end(ds_handle *h, int *n_launches, double *total_ms, double *min_ms, double *max_ms);
+
+/* Geometry of the handle (any pointer may be NULL). */
+int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_begin, int *row_end);
+
+/* Order-independent 64-bit checksum of the band's phi (sum of the bit patterns of
+ * all entries the reference would touch), to compare large states without copying. */
+int ds_checksum(ds_handle *h, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSTEREO_H */

@@ -1,0 +1,150 @@
+"""Row-band data parallelism for the diffusion sweep: one process (rank) per GPU.
+
+The reference is single-process (diffusion_stereo/src/diffusion_graph.rs:264-293 is one
+raster loop); under the red-black schedule a pixel update reads only the four opposite
+colour neighbours, so the image splits into horizontal bands that exchange ONE row of
+messages with each neighbouring band after each colour's half-sweep:
+
+  after colour c:  first band row's slot-1 (upward) messages  -> band above (its bottom halo)
+                   last band row's slot-3 (downward) messages -> band below (its top halo)
+
+That point-to-point exchange (torch.distributed isend/irecv: RCCL over xGMI on GPUs,
+gloo on CPU) is the only communication; the energy is a sum of per-band energies
+(all_reduce).  The boundary rows are swept first so that the exchange overlaps the
+sweep of the interior rows.  The result is bit-identical to the single-band result:
+each pixel sees exactly the same operands.
+
+`BandRunner` is engine-agnostic: the engine supplies the sweep and the halo buffers.
+`HipBandEngine` is the product engine (C ABI of include/diffstereo.h).
+"""
+import torch
+import torch.distributed as dist
+
+
+def partition_rows(H, n_bands):
+    """Contiguous near-equal bands [(row_begin, row_end)]; every band gets >= 1 row."""
+    if n_bands < 1 or n_bands > H:
+        raise ValueError("need 1 <= n_bands <= H (got %d bands for %d rows)" % (n_bands, H))
+    base, extra = divmod(H, n_bands)
+    out, r = [], 0
+    for b in range(n_bands):
+        k = base + (1 if b < extra else 0)
+        out.append((r, r + k))
+        r += k
+    return out
+
+
+class _DeviceBytes:
+    """Zero-copy view of library-owned device memory for torch.as_tensor."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
+                                         "data": (ptr, False), "version": 2}
+
+
+class HipBandEngine:
+    """One band on the current GPU, driven through the C ABI."""
+
+    def __init__(self, graph, stage_through_host=False):
+        self.g = graph
+        self.row_begin, self.row_end = graph.row_begin, graph.row_end
+        self.H = graph.H
+        self.stage = stage_through_host  # gloo rehearsal: halos travel via pinned host copies
+        self._views = {}
+        graph.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def _view(self, colour, side, which):
+        key = (colour, side, which)
+        if key not in self._views:
+            ptr, nbytes = self.g.halo(colour, side, which)
+            self._views[key] = torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
+        return self._views[key]
+
+    def sweep(self, colour, row_begin, row_end):
+        if row_end > row_begin:
+            self.g.sweep(colour, row_begin, row_end)
+
+    def send_buffer(self, colour, side):
+        v = self._view(colour, side, 0)
+        return v.cpu() if self.stage else v
+
+    def recv_buffer(self, colour, side):
+        v = self._view(colour, side, 1)
+        return torch.empty(v.shape, dtype=v.dtype) if self.stage else v
+
+    def commit_recv(self, colour, side, buf):
+        if self.stage:
+            self._view(colour, side, 1).copy_(buf)
+
+    def energy(self):
+        return self.g.energy()
+
+    def synchronize(self):
+        torch.cuda.current_stream().synchronize()
+
+
+class BandRunner:
+    """Runs checkerboard iterations on this rank's band and keeps the halos current."""
+
+    def __init__(self, engine, rank=None, world=None, group=None):
+        self.e = engine
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.up = self.rank - 1 if self.rank > 0 else None
+        self.down = self.rank + 1 if self.rank + 1 < self.world else None
+
+    def _post(self, colour):
+        """Queue this colour's halo exchange; returns (requests, receive buffers)."""
+        ops, recvs = [], []
+        for side, peer in ((0, self.up), (1, self.down)):
+            if peer is None:
+                continue
+            ops.append(dist.P2POp(dist.isend, self.e.send_buffer(colour, side), peer, self.group))
+            rb = self.e.recv_buffer(colour, side)
+            recvs.append((side, rb))
+            ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
+        return (dist.batch_isend_irecv(ops) if ops else []), recvs
+
+    def half_sweep(self, colour):
+        e = self.e
+        rb, re = e.row_begin, e.row_end
+        if self.world == 1:
+            e.sweep(colour, rb, re)
+            return
+        # boundary rows first, so the exchange overlaps the interior rows
+        top_end = min(rb + 1, re) if self.up is not None else rb
+        bot_begin = max(re - 1, top_end) if self.down is not None else re
+        e.sweep(colour, rb, top_end)
+        e.sweep(colour, bot_begin, re)
+        reqs, recvs = self._post(colour)
+        e.sweep(colour, top_end, bot_begin)
+        for r in reqs:
+            r.wait()
+        for side, buf in recvs:
+            e.commit_recv(colour, side, buf)
+
+    def iterate(self, n_iters):
+        for _ in range(n_iters):
+            self.half_sweep(0)
+            self.half_sweep(1)
+
+    def exchange_all(self):
+        """Bring both colours' halos up to date (after set_phi on the bands)."""
+        if self.world == 1:
+            return
+        for colour in (0, 1):
+            reqs, recvs = self._post(colour)
+            for r in reqs:
+                r.wait()
+            for side, buf in recvs:
+                self.e.commit_recv(colour, side, buf)
+
+    def energy(self):
+        """Energy of the whole image (diffusion_graph.rs:502-518): sum over bands."""
+        t = torch.tensor([self.e.energy()], dtype=torch.float64)
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())

@@ -1,0 +1,600 @@
+// Host side of libdiffstereo: handle management, launches and the extern "C" ABI
+// declared in include/diffstereo.h.  Device code lives in kernels.hpp.
+#include "../../include/diffstereo.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct ds_handle {
+    ds::Geometry g{};
+    int dtype = DS_F32;
+    double lambda = 0.0;
+    int device = 0;
+    int lpp = 64;         // lanes per pixel
+    int seg_pixels = 64;  // same-colour pixels per block
+    int grid_x = 1;
+
+    uint8_t *d_left = nullptr, *d_right = nullptr;  // [H][W]
+    uint8_t *cost_lm = nullptr;                     // [D][Hb][W] (+3 bytes padding)
+    uint8_t *cost_px = nullptr;                     // [2][Hb][Wh][Dpad]
+    void *phi = nullptr;                            // [2][4][Hb+2][Wh][Dpad]
+    size_t elem = 4;
+
+    double *part_sum = nullptr, *part_max = nullptr;  // per-wavefront partials
+    long long part_n = 0;
+    double *d_scalars = nullptr;                      // [0] energy, [1] max residual
+    unsigned long long *d_checksum = nullptr;
+    uint32_t *d_labels = nullptr;                     // [Hb][W]
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    bool prof = false;
+    int prof_cap = 0, prof_n = 0;
+    std::vector<hipEvent_t> events;
+
+    std::string err;
+};
+
+namespace {
+
+int fail(ds_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+int fail_hip(ds_handle *h, const char *what, hipError_t e)
+{
+    return fail(h, DS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIPCHK(h, call)                                         \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return fail_hip(h, #call, e_);    \
+    } while (0)
+
+template <typename F> int guarded(ds_handle *h, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(h, DS_ERR_NOMEM, "host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(h, DS_ERR_STATE, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(h, DS_ERR_STATE, "internal error");
+    }
+}
+
+// Calls f(T{}, std::integral_constant<int, LPP>{}) for the handle's dtype and lane split.
+template <typename F> int dispatch(ds_handle *h, F &&f)
+{
+    auto with_t = [&](auto t) -> int {
+        switch (h->lpp) {
+        case 16: return f(t, std::integral_constant<int, 16>{});
+        case 32: return f(t, std::integral_constant<int, 32>{});
+        default: return f(t, std::integral_constant<int, 64>{});
+        }
+    };
+    return h->dtype == DS_F64 ? with_t(double{}) : with_t(float{});
+}
+
+long long phi_elems(const ds::Geometry &g) { return 2 * g.colour_stride; }
+
+int use_device(ds_handle *h)
+{
+    HIPCHK(h, hipSetDevice(h->device));
+    return DS_OK;
+}
+
+void release(ds_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    (void)hipFree(h->d_left);
+    (void)hipFree(h->d_right);
+    (void)hipFree(h->cost_lm);
+    (void)hipFree(h->cost_px);
+    (void)hipFree(h->phi);
+    (void)hipFree(h->part_sum);
+    (void)hipFree(h->part_max);
+    (void)hipFree(h->d_scalars);
+    (void)hipFree(h->d_checksum);
+    (void)hipFree(h->d_labels);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int launch_sweep(ds_handle *h, int colour, int row_begin, int row_end)
+{
+    const int rows = row_end - row_begin;
+    if (rows <= 0) return DS_OK;
+    const bool timed = h->prof && h->prof_n < h->prof_cap;
+    if (timed) HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
+    const dim3 grid(h->grid_x, rows), block(ds::kBlock);
+    int rc = dispatch(h, [&](auto t, auto lpp) -> int {
+        using T = decltype(t);
+        hipLaunchKernelGGL((ds::sweep_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, h->g,
+                           static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin,
+                           h->seg_pixels);
+        return DS_OK;
+    });
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipGetLastError());
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n + 1], h->stream));
+        ++h->prof_n;
+    }
+    return DS_OK;
+}
+
+int build_cost(ds_handle *h)
+{
+    const ds::Geometry &g = h->g;
+    const long long total = (long long)g.D * g.Hb * g.W;
+    const long long threads = (total + 3) / 4;
+    const unsigned blocks = (unsigned)((threads + ds::kBlock - 1) / ds::kBlock);
+    hipLaunchKernelGGL(ds::cost_volume_kernel, dim3(blocks), dim3(ds::kBlock), 0, h->stream, h->d_left,
+                       h->d_right, g.W, g.D, g.row0, g.Hb, h->cost_lm);
+    HIPCHK(h, hipGetLastError());
+    const dim3 grid((g.W + ds::kPackCols - 1) / ds::kPackCols, g.Hb);
+    const size_t lds = (size_t)ds::kPackCols * (g.Dpad + 4);
+    hipLaunchKernelGGL(ds::pack_cost_kernel, grid, dim3(ds::kBlock), lds, h->stream, g, h->cost_lm,
+                       h->cost_px);
+    HIPCHK(h, hipGetLastError());
+    return DS_OK;
+}
+
+int init_phi(ds_handle *h)
+{
+    const long long total = phi_elems(h->g);
+    long long blocks = (total + ds::kBlock - 1) / ds::kBlock;
+    if (blocks > 65536) blocks = 65536;
+    if (h->dtype == DS_F64)
+        hipLaunchKernelGGL(ds::init_phi_kernel<double>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
+                           h->stream, h->g, static_cast<double *>(h->phi));
+    else
+        hipLaunchKernelGGL(ds::init_phi_kernel<float>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
+                           h->stream, h->g, static_cast<float *>(h->phi));
+    HIPCHK(h, hipGetLastError());
+    return DS_OK;
+}
+
+int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, double lambda, int dtype,
+           int row_begin, int row_end, int device, ds_handle **out)
+{
+    if (!out) return fail(nullptr, DS_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!left || !right) return fail(nullptr, DS_ERR_ARG, "image pointer is NULL");
+    if (H < 1 || W < 1) return fail(nullptr, DS_ERR_ARG, "H and W must be >= 1");
+    if (D < 1 || D > 256) return fail(nullptr, DS_ERR_ARG, "D must be in [1, 256]");
+    if (dtype != DS_F32 && dtype != DS_F64) return fail(nullptr, DS_ERR_ARG, "dtype must be DS_F32 or DS_F64");
+    if (!(lambda == lambda) || std::isinf(lambda)) return fail(nullptr, DS_ERR_ARG, "lambda must be finite");
+    if (row_begin < 0 || row_end > H || row_begin >= row_end)
+        return fail(nullptr, DS_ERR_ARG, "band must satisfy 0 <= row_begin < row_end <= H");
+
+    ds_handle *h = new ds_handle();
+    if (device < 0) {
+        hipError_t e = hipGetDevice(&h->device);
+        if (e != hipSuccess) {
+            delete h;
+            return fail_hip(nullptr, "hipGetDevice", e);
+        }
+    } else {
+        h->device = device;
+    }
+    auto bail = [&](int rc) {
+        g_create_error = h->err;
+        release(h);
+        return rc;
+    };
+    int rc = use_device(h);
+    if (rc != DS_OK) return bail(rc);
+
+    ds::Geometry &g = h->g;
+    g.H = H; g.W = W; g.D = D;
+    g.Dpad = (D + 3) & ~3;
+    g.Wh = (W + 1) / 2;
+    g.row0 = row_begin;
+    g.Hb = row_end - row_begin;
+    g.dir_stride = (long long)(g.Hb + 2) * g.Wh * g.Dpad;
+    g.colour_stride = 4 * g.dir_stride;
+    g.cost_colour_stride = (long long)g.Hb * g.Wh * g.Dpad;
+    h->dtype = dtype;
+    h->elem = dtype == DS_F64 ? 8 : 4;
+    h->lambda = lambda;
+    h->lpp = g.Dpad <= 64 ? 16 : g.Dpad <= 128 ? 32 : 64;
+    {
+        const int ppw = 64 / h->lpp;
+        const int per_round = (ds::kBlock / 64) * ppw;  // pixels one pass of the block's 4 waves covers
+        int rounds = (g.Wh + per_round - 1) / per_round;
+        if (rounds > 16) rounds = 16;
+        if (rounds < 1) rounds = 1;
+        h->seg_pixels = rounds * per_round;
+        h->grid_x = (g.Wh + h->seg_pixels - 1) / h->seg_pixels;
+    }
+
+#define CREATE_HIPCHK(call)                                                    \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) {                                                \
+            int rc_ = e_ == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP;   \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);        \
+            return bail(rc_);                                                  \
+        }                                                                      \
+    } while (0)
+
+    CREATE_HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    const size_t img = (size_t)H * W;
+    CREATE_HIPCHK(hipMalloc(&h->d_left, img));
+    CREATE_HIPCHK(hipMalloc(&h->d_right, img));
+    CREATE_HIPCHK(hipMemcpyAsync(h->d_left, left, img, hipMemcpyHostToDevice, h->stream));
+    CREATE_HIPCHK(hipMemcpyAsync(h->d_right, right, img, hipMemcpyHostToDevice, h->stream));
+    CREATE_HIPCHK(hipMalloc(&h->cost_lm, (size_t)D * g.Hb * W + 4));
+    CREATE_HIPCHK(hipMalloc(&h->cost_px, (size_t)(2 * g.cost_colour_stride)));
+    CREATE_HIPCHK(hipMalloc(&h->phi, (size_t)phi_elems(g) * h->elem));
+    h->part_n = 2ll * h->grid_x * g.Hb * (ds::kBlock / 64);
+    CREATE_HIPCHK(hipMalloc(&h->part_sum, (size_t)h->part_n * sizeof(double)));
+    CREATE_HIPCHK(hipMalloc(&h->part_max, (size_t)h->part_n * sizeof(double)));
+    CREATE_HIPCHK(hipMalloc(&h->d_scalars, 2 * sizeof(double)));
+    CREATE_HIPCHK(hipMalloc(&h->d_checksum, sizeof(unsigned long long)));
+    CREATE_HIPCHK(hipMalloc(&h->d_labels, (size_t)g.Hb * W * sizeof(uint32_t)));
+#undef CREATE_HIPCHK
+
+    rc = build_cost(h);
+    if (rc == DS_OK) rc = init_phi(h);
+    if (rc == DS_OK) {
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail_hip(h, "hipStreamSynchronize", e);
+    }
+    if (rc != DS_OK) return bail(rc);
+    *out = h;
+    return DS_OK;
+}
+
+// Host <-> device conversion between the reference layout [rows][W][4][D] and the
+// colour-split device layout, for image rows [rb, re) (halo rows allowed).
+template <typename T> int copy_phi_rows(ds_handle *h, int rb, int re, T *host_out, const T *host_in)
+{
+    const ds::Geometry &g = h->g;
+    const int rows = re - rb;
+    const long long chunk = (long long)rows * g.Wh * g.Dpad;  // per (colour, slot)
+    std::vector<T> stage((size_t)(8 * chunk));
+    const long long first = (long long)(rb - g.row0 + 1) * g.Wh * g.Dpad;
+    T *dev = static_cast<T *>(h->phi);
+    const T inf = std::numeric_limits<T>::infinity();
+    if (host_out) {
+        for (int p = 0; p < 8; ++p)
+            HIPCHK(h, hipMemcpyAsync(stage.data() + p * chunk, dev + p * g.dir_stride + first,
+                                     (size_t)chunk * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+        for (auto &x : stage) x = inf;
+    }
+    for (int r = 0; r < rows; ++r) {
+        const int i = rb + r;
+        for (int j = 0; j < g.W; ++j) {
+            const int colour = (i + j) & 1, jc = j >> 1;
+            const int K = j < g.D - 1 ? j : g.D - 1;
+            for (int n = 0; n < 4; ++n) {
+                T *s = stage.data() + (colour * 4 + n) * chunk + ((long long)r * g.Wh + jc) * g.Dpad;
+                const long long hoff = (((long long)r * g.W + j) * 4 + n) * g.D;
+                if (host_out) {
+                    for (int d = 0; d < g.D; ++d) host_out[hoff + d] = d <= K ? s[d] : T(0);
+                } else {
+                    for (int d = 0; d <= K; ++d) s[d] = host_in[hoff + d];
+                }
+            }
+        }
+    }
+    if (host_in) {
+        for (int p = 0; p < 8; ++p)
+            HIPCHK(h, hipMemcpyAsync(dev + p * g.dir_stride + first, stage.data() + p * chunk,
+                                     (size_t)chunk * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return DS_OK;
+}
+
+int phi_rows(ds_handle *h, int rb, int re, void *out, const void *in)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!out && !in) return fail(h, DS_ERR_ARG, "buffer is NULL");
+    const ds::Geometry &g = h->g;
+    const int lo = g.row0 > 0 ? g.row0 - 1 : 0;
+    const int hi = g.row0 + g.Hb < g.H ? g.row0 + g.Hb + 1 : g.H;
+    if (rb < lo || re > hi || rb > re) return fail(h, DS_ERR_ARG, "row range outside the band and its halo");
+    if (rb == re) return DS_OK;
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    return guarded(h, [&]() -> int {
+        if (h->dtype == DS_F64)
+            return copy_phi_rows<double>(h, rb, re, static_cast<double *>(out), static_cast<const double *>(in));
+        return copy_phi_rows<float>(h, rb, re, static_cast<float *>(out), static_cast<const float *>(in));
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_create(const uint8_t *left, const uint8_t *right, int H, int W, int D, double lambda, int dtype,
+              ds_handle **out)
+{
+    return guarded(nullptr, [&]() { return create(left, right, H, W, D, lambda, dtype, 0, H, -1, out); });
+}
+
+int ds_create_band(const uint8_t *left, const uint8_t *right, int H, int W, int D, double lambda,
+                   int dtype, int row_begin, int row_end, int device, ds_handle **out)
+{
+    return guarded(nullptr, [&]() {
+        return create(left, right, H, W, D, lambda, dtype, row_begin, row_end, device, out);
+    });
+}
+
+void ds_destroy(ds_handle *h) { release(h); }
+
+const char *ds_last_error(const ds_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ds_set_stream(ds_handle *h, void *hip_stream)
+{
+    if (!h) return DS_ERR_ARG;
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return DS_OK;
+}
+
+int ds_synchronize(ds_handle *h)
+{
+    if (!h) return DS_ERR_ARG;
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DS_OK;
+}
+
+int ds_build_cost(ds_handle *h)
+{
+    if (!h) return DS_ERR_ARG;
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    rc = build_cost(h);
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DS_OK;
+}
+
+int ds_get_cost(ds_handle *h, uint8_t *out)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!out) return fail(h, DS_ERR_ARG, "out is NULL");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    const size_t bytes = (size_t)h->g.D * h->g.Hb * h->g.W;
+    HIPCHK(h, hipMemcpyAsync(out, h->cost_lm, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DS_OK;
+}
+
+int ds_sweep(ds_handle *h, int colour, int row_begin, int row_end)
+{
+    if (!h) return DS_ERR_ARG;
+    if (colour != 0 && colour != 1) return fail(h, DS_ERR_ARG, "colour must be 0 or 1");
+    if (row_begin < h->g.row0 || row_end > h->g.row0 + h->g.Hb || row_begin > row_end)
+        return fail(h, DS_ERR_ARG, "rows outside the handle's band");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    return launch_sweep(h, colour, row_begin, row_end);
+}
+
+int ds_iterate(ds_handle *h, int n_iters)
+{
+    if (!h) return DS_ERR_ARG;
+    if (n_iters < 0) return fail(h, DS_ERR_ARG, "n_iters must be >= 0");
+    if (h->g.row0 != 0 || h->g.Hb != h->g.H)
+        return fail(h, DS_ERR_STATE, "ds_iterate needs the whole image; a band must use ds_sweep + halo exchange");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    for (int it = 0; it < n_iters; ++it)
+        for (int colour = 0; colour < 2; ++colour) {
+            rc = launch_sweep(h, colour, 0, h->g.H);
+            if (rc != DS_OK) return rc;
+        }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DS_OK;
+}
+
+int ds_energy(ds_handle *h, double *energy, double *max_residual)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!energy) return fail(h, DS_ERR_ARG, "energy is NULL");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    const dim3 grid(h->grid_x, h->g.Hb), block(ds::kBlock);
+    const long long half = h->part_n / 2;
+    HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 2 * sizeof(double), h->stream));
+    for (int colour = 0; colour < 2; ++colour) {
+        rc = dispatch(h, [&](auto t, auto lpp) -> int {
+            using T = decltype(t);
+            hipLaunchKernelGGL((ds::energy_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream,
+                               h->g, static_cast<const T *>(h->phi), h->cost_px, (T)h->lambda, colour,
+                               h->seg_pixels, h->part_sum + colour * half, h->part_max + colour * half);
+            return DS_OK;
+        });
+        if (rc != DS_OK) return rc;
+        HIPCHK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(ds::reduce_partials_kernel, dim3(1), block, 0, h->stream, h->part_sum, h->part_max,
+                       h->part_n, h->d_scalars, h->d_scalars + 1);
+    HIPCHK(h, hipGetLastError());
+    double host[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(host, h->d_scalars, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *energy = host[0];
+    if (max_residual) *max_residual = host[1];
+    return DS_OK;
+}
+
+int ds_labels(ds_handle *h, int mode, uint32_t *out)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!out) return fail(h, DS_ERR_ARG, "out is NULL");
+    if (mode != 0 && mode != 1) return fail(h, DS_ERR_ARG, "mode must be 0 or 1");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    const dim3 grid(h->grid_x, h->g.Hb), block(ds::kBlock);
+    for (int colour = 0; colour < 2; ++colour) {
+        rc = dispatch(h, [&](auto t, auto lpp) -> int {
+            using T = decltype(t);
+            hipLaunchKernelGGL((ds::labels_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream,
+                               h->g, static_cast<const T *>(h->phi), h->cost_px, (T)h->lambda, colour,
+                               h->seg_pixels, mode, h->d_labels);
+            return DS_OK;
+        });
+        if (rc != DS_OK) return rc;
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipMemcpyAsync(out, h->d_labels, (size_t)h->g.Hb * h->g.W * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DS_OK;
+}
+
+int ds_get_phi_rows(ds_handle *h, int row_begin, int row_end, void *out)
+{
+    return phi_rows(h, row_begin, row_end, out, nullptr);
+}
+
+int ds_set_phi_rows(ds_handle *h, int row_begin, int row_end, const void *in)
+{
+    return phi_rows(h, row_begin, row_end, nullptr, in);
+}
+
+int ds_get_phi(ds_handle *h, void *out)
+{
+    if (!h) return DS_ERR_ARG;
+    return phi_rows(h, h->g.row0, h->g.row0 + h->g.Hb, out, nullptr);
+}
+
+int ds_set_phi(ds_handle *h, const void *in)
+{
+    if (!h) return DS_ERR_ARG;
+    return phi_rows(h, h->g.row0, h->g.row0 + h->g.Hb, nullptr, in);
+}
+
+int ds_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_t *bytes)
+{
+    if (!h) return DS_ERR_ARG;
+    if ((colour | 1) != 1 || (side | 1) != 1 || (which | 1) != 1 || !dev_ptr || !bytes)
+        return fail(h, DS_ERR_ARG, "bad ds_halo argument");
+    const ds::Geometry &g = h->g;
+    // top: send slot 1 of band row 1, receive slot 3 into halo row 0;
+    // bottom: send slot 3 of band row Hb, receive slot 1 into halo row Hb + 1.
+    const int slot = side == 0 ? (which == 0 ? 1 : 3) : (which == 0 ? 3 : 1);
+    const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
+    const long long off = colour * g.colour_stride + slot * g.dir_stride + (long long)il * g.Wh * g.Dpad;
+    *dev_ptr = static_cast<char *>(h->phi) + (size_t)off * h->elem;
+    *bytes = (size_t)g.Wh * g.Dpad * h->elem;
+    return DS_OK;
+}
+
+int ds_profile_begin(ds_handle *h, int max_launches)
+{
+    if (!h) return DS_ERR_ARG;
+    if (max_launches < 1 || max_launches > (1 << 20)) return fail(h, DS_ERR_ARG, "max_launches out of range");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    return guarded(h, [&]() -> int {
+        while ((int)h->events.size() < 2 * max_launches) {
+            hipEvent_t e;
+            HIPCHK(h, hipEventCreate(&e));
+            h->events.push_back(e);
+        }
+        h->prof_cap = max_launches;
+        h->prof_n = 0;
+        h->prof = true;
+        return DS_OK;
+    });
+}
+
+int ds_profile_end(ds_handle *h, int *n_launches, double *total_ms, double *min_ms, double *max_ms)
+{
+    if (!h) return DS_ERR_ARG;
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    h->prof = false;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double tot = 0, lo = 0, hi = 0;
+    for (int k = 0; k < h->prof_n; ++k) {
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->events[2 * k], h->events[2 * k + 1]));
+        tot += ms;
+        lo = k == 0 ? ms : (ms < lo ? ms : lo);
+        hi = k == 0 ? ms : (ms > hi ? ms : hi);
+    }
+    if (n_launches) *n_launches = h->prof_n;
+    if (total_ms) *total_ms = tot;
+    if (min_ms) *min_ms = lo;
+    if (max_ms) *max_ms = hi;
+    return DS_OK;
+}
+
+int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_begin, int *row_end)
+{
+    if (!h) return DS_ERR_ARG;
+    if (H) *H = h->g.H;
+    if (W) *W = h->g.W;
+    if (D) *D = h->g.D;
+    if (dtype) *dtype = h->dtype;
+    if (row_begin) *row_begin = h->g.row0;
+    if (row_end) *row_end = h->g.row0 + h->g.Hb;
+    return DS_OK;
+}
+
+int ds_checksum(ds_handle *h, uint64_t *out)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!out) return fail(h, DS_ERR_ARG, "out is NULL");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_checksum, 0, sizeof(unsigned long long), h->stream));
+    long long blocks = (phi_elems(h->g) + ds::kBlock - 1) / ds::kBlock;
+    if (blocks > 16384) blocks = 16384;
+    if (h->dtype == DS_F64)
+        hipLaunchKernelGGL(ds::checksum_kernel<double>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
+                           h->stream, h->g, static_cast<const double *>(h->phi), h->d_checksum);
+    else
+        hipLaunchKernelGGL(ds::checksum_kernel<float>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
+                           h->stream, h->g, static_cast<const float *>(h->phi), h->d_checksum);
+    HIPCHK(h, hipGetLastError());
+    unsigned long long v = 0;
+    HIPCHK(h, hipMemcpyAsync(&v, h->d_checksum, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *out = v;
+    return DS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,651 @@
+// Device code of the diffusion_stereo hot path for gfx950 (MI355X, wave64).
+//
+// Work decomposition (all kernels): labels d run across lanes, 4 consecutive
+// labels per lane, so one pixel occupies a segment of LPP lanes (LPP = 16, 32 or
+// 64 for D <= 64, 128, 256) and a wavefront holds 64/LPP pixels at a time.  All
+// phi rows are stored d-fastest, so every global access is a 16-byte (f32) or
+// 32-byte (f64) per-lane vector and a wavefront instruction moves one contiguous
+// kilobyte.  The min-plus products over d are prefix / suffix minima evaluated
+// with DPP cross-lane moves; they are HBM-bound scans, not contractions, so no
+// MFMA is involved.
+//
+// Device layout of phi ("colour split"): phi[colour][slot][band row + halo][jc][dp]
+//   colour = (i + j) & 1, jc = j >> 1 (pixels of one colour are contiguous),
+//   dp in [0, Dpad), Dpad = D rounded up to a multiple of 4.
+// Entries the reference never touches (d > j, and the padding dp >= D) hold +inf,
+// which makes every masked min a plain min: +inf only ever meets finite addends
+// (x - lambda*d, x + lambda*d), never another infinity, on paths that are stored.
+//
+// Update rule (reference: diffusion_stereo/src/diffusion_graph.rs:135-141,152-169,
+// 212-251,302-341), per pixel t, slot n with neighbour t' and reverse slot n':
+//   psi_n    = phi[t'][n'][.]
+//   M_n(d)   = min over allowed d' of ( lambda*|d-d'| + psi_n(d') )
+//   phi[t][n][d] <- ( q_t(d) + sum_m M_m(d) ) / |N(t)| - M_n(d)
+// "allowed" = edge_exists: d' <= d+1 for the right neighbour (slot 2), d' >= d-1
+// for the left one (slot 0), no constraint vertically (slots 1, 3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ds {
+
+struct Geometry {
+    int H, W, D;      // whole image, number of labels
+    int Dpad;         // D rounded up to a multiple of 4
+    int Wh;           // (W + 1) / 2: pixel slots per colour per row
+    int row0, Hb;     // band: image rows [row0, row0 + Hb)
+    long long dir_stride;          // elements per (colour, slot): (Hb + 2) * Wh * Dpad
+    long long colour_stride;       // 4 * dir_stride
+    long long cost_colour_stride;  // bytes per colour of the packed cost: Hb * Wh * Dpad
+};
+
+constexpr int kBlock = 256;  // 4 wavefronts
+
+template <typename T> struct Real;
+template <> struct Real<float> {
+    static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+    static __device__ __forceinline__ float min(float a, float b) { return __builtin_fminf(a, b); }
+    static __device__ __forceinline__ float abs(float a) { return __builtin_fabsf(a); }
+};
+template <> struct Real<double> {
+    static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+    static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double abs(double a) { return __builtin_fabs(a); }
+};
+
+// ---- 4-label vectors ----------------------------------------------------------
+template <typename T> struct V4 { T v[4]; };
+
+__device__ __forceinline__ V4<float> load4(const float *p)
+{
+    float4 x = *reinterpret_cast<const float4 *>(p);
+    return {{x.x, x.y, x.z, x.w}};
+}
+__device__ __forceinline__ V4<double> load4(const double *p)
+{
+    double2 a = *reinterpret_cast<const double2 *>(p);
+    double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    return {{a.x, a.y, b.x, b.y}};
+}
+__device__ __forceinline__ void store4(float *p, const V4<float> &x)
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+}
+__device__ __forceinline__ void store4(double *p, const V4<double> &x)
+{
+    *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[1]);
+    *reinterpret_cast<double2 *>(p + 2) = make_double2(x.v[2], x.v[3]);
+}
+template <typename T> __device__ __forceinline__ V4<T> splat(T x) { return {{x, x, x, x}}; }
+
+// ---- DPP cross-lane moves (gfx9 encodings) ----------------------------------------
+// Lanes whose source lane does not exist (shifted off the row / wave) or that the
+// row mask disables keep `old`.
+constexpr int DPP_ROW_SHL = 0x100;   // + n: lane l reads lane l+n of its 16-lane row
+constexpr int DPP_ROW_SHR = 0x110;   // + n: lane l reads lane l-n of its 16-lane row
+constexpr int DPP_WAVE_SHL1 = 0x130; // lane l reads lane l+1 of the wavefront
+constexpr int DPP_WAVE_SHR1 = 0x138; // lane l reads lane l-1 of the wavefront
+constexpr int DPP_ROW_BCAST15 = 0x142; // lane 15 of each row to every lane of the next row
+constexpr int DPP_ROW_BCAST31 = 0x143; // lane 31 to every lane of rows 2 and 3
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp(double old, double src)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane(float x, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+__device__ __forceinline__ double readlane(double x, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// min over the lanes strictly below this one inside its LPP-lane segment (+inf for the first).
+template <typename T, int LPP>
+__device__ __forceinline__ T excl_prefix_min(T v, int lseg)
+{
+    using R = Real<T>;
+    const T inf = R::inf();
+    T e = dpp<DPP_WAVE_SHR1>(inf, v);
+    if (LPP < 64) e = (lseg == 0) ? inf : e;
+    e = R::min(e, dpp<DPP_ROW_SHR + 1>(inf, e));
+    e = R::min(e, dpp<DPP_ROW_SHR + 2>(inf, e));
+    e = R::min(e, dpp<DPP_ROW_SHR + 4>(inf, e));
+    e = R::min(e, dpp<DPP_ROW_SHR + 8>(inf, e));
+    if (LPP >= 32) e = R::min(e, dpp<DPP_ROW_BCAST15, 0xa>(inf, e));
+    if (LPP >= 64) e = R::min(e, dpp<DPP_ROW_BCAST31, 0xc>(inf, e));
+    return e;
+}
+
+// min over the lanes strictly above this one inside its LPP-lane segment (+inf for the last).
+template <typename T, int LPP>
+__device__ __forceinline__ T excl_suffix_min(T v, int lseg, int lane)
+{
+    using R = Real<T>;
+    const T inf = R::inf();
+    T e = dpp<DPP_WAVE_SHL1>(inf, v);
+    if (LPP < 64) e = (lseg == LPP - 1) ? inf : e;
+    e = R::min(e, dpp<DPP_ROW_SHL + 1>(inf, e));
+    e = R::min(e, dpp<DPP_ROW_SHL + 2>(inf, e));
+    e = R::min(e, dpp<DPP_ROW_SHL + 4>(inf, e));
+    e = R::min(e, dpp<DPP_ROW_SHL + 8>(inf, e));
+    // e(l) now covers the rest of the lane's 16-lane row; add the rows above it.
+    if (LPP >= 32) {
+        const int row = lane >> 4;
+        const T t1 = readlane(e, 16), t3 = readlane(e, 48);
+        T add;
+        if (LPP >= 64) {
+            const T t2 = readlane(e, 32);
+            const T c23 = R::min(t2, t3), c123 = R::min(t1, c23);
+            add = row == 0 ? c123 : row == 1 ? c23 : row == 2 ? t3 : inf;
+        } else {
+            add = row == 0 ? t1 : row == 2 ? t3 : inf;
+        }
+        e = R::min(e, add);
+    }
+    return e;
+}
+
+// ---- the four messages of one pixel --------------------------------------------
+// psi[n] = the neighbour's reverse row (4 labels of this lane; +inf where invalid or
+// where the neighbour does not exist), lam[k] = fl(lambda * d_k), lam1 = lambda.
+template <typename T, int LPP>
+__device__ __forceinline__ void messages(const V4<T> psi[4], const T lam[4], T lam1, int lseg, int lane,
+                                         V4<T> M[4])
+{
+    using R = Real<T>;
+    const T inf = R::inf();
+    T fwd[4], bwd[4];
+
+    // forward part min_{d'<=d}: slots 1, 2, 3
+    auto forward = [&](const V4<T> &x) {
+        T p[4];
+        p[0] = x.v[0] - lam[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) p[k] = R::min(p[k - 1], x.v[k] - lam[k]);
+        const T xf = excl_prefix_min<T, LPP>(p[3], lseg);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fwd[k] = R::min(p[k], xf) + lam[k];
+    };
+    // backward part min_{d'>=d}: slots 0, 1, 3
+    auto backward = [&](const V4<T> &x) {
+        T s[4];
+        s[3] = x.v[3] + lam[3];
+#pragma unroll
+        for (int k = 2; k >= 0; --k) s[k] = R::min(s[k + 1], x.v[k] + lam[k]);
+        const T xb = excl_suffix_min<T, LPP>(s[0], lseg, lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bwd[k] = R::min(s[k], xb) - lam[k];
+    };
+
+    // slot 0 (left neighbour): d' >= d-1
+    {
+        backward(psi[0]);
+        T prev = dpp<DPP_WAVE_SHR1>(inf, psi[0].v[3]);
+        if (LPP < 64) prev = (lseg == 0) ? inf : prev;
+        M[0].v[0] = R::min(bwd[0], lam1 + prev);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) M[0].v[k] = R::min(bwd[k], lam1 + psi[0].v[k - 1]);
+    }
+    // slots 1 and 3 (vertical): unconstrained
+#pragma unroll
+    for (int n = 1; n < 4; n += 2) {
+        forward(psi[n]);
+        backward(psi[n]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) M[n].v[k] = R::min(fwd[k], bwd[k]);
+    }
+    // slot 2 (right neighbour): d' <= d+1
+    {
+        forward(psi[2]);
+        T next = dpp<DPP_WAVE_SHL1>(inf, psi[2].v[0]);
+        if (LPP < 64) next = (lseg == LPP - 1) ? inf : next;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M[2].v[k] = R::min(fwd[k], lam1 + psi[2].v[k + 1]);
+        M[2].v[3] = R::min(fwd[3], lam1 + next);
+    }
+}
+
+// Everything a lane needs to know about "its" pixel for one step.
+struct Pixel {
+    bool active;       // pixel exists and the lane's 4 labels lie inside Dpad
+    bool has[4];       // neighbour slot exists (utils.rs:42-67)
+    int nn;            // |N(t)|
+    int j;             // column
+    long long own;     // element offset of (il, jc, d0) inside one (colour, slot) plane
+    long long nb[4];   // same, for the neighbour read through slot n
+    long long cost;    // byte offset into the packed cost of this colour
+};
+
+// i = image row, il = row inside the band's buffer (halo row above = 0), s = column of
+// the row's first pixel of this colour, jc = pixel slot, d0 = first label of the lane.
+__device__ __forceinline__ Pixel locate(const Geometry &g, int i, int s, int jc, int d0)
+{
+    Pixel p;
+    const int il = i - g.row0 + 1;
+    p.j = 2 * jc + s;
+    p.active = (p.j < g.W) && (d0 < g.Dpad);
+    p.has[0] = p.j > 0;
+    p.has[1] = i > 0;
+    p.has[2] = p.j + 1 < g.W;
+    p.has[3] = i + 1 < g.H;
+    p.nn = (int)p.has[0] + (int)p.has[1] + (int)p.has[2] + (int)p.has[3];
+    const long long row = (long long)il * g.Wh;
+    p.own = (row + jc) * g.Dpad + d0;
+    p.nb[0] = (row + jc + s - 1) * g.Dpad + d0;          // (i, j-1): slot jc + s - 1
+    p.nb[1] = (row - g.Wh + jc) * g.Dpad + d0;           // (i-1, j): slot jc
+    p.nb[2] = (row + jc + s) * g.Dpad + d0;              // (i, j+1): slot jc + s
+    p.nb[3] = (row + g.Wh + jc) * g.Dpad + d0;           // (i+1, j): slot jc
+    p.cost = ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0;
+    return p;
+}
+
+__device__ __forceinline__ int reverse_slot(int n) { return n ^ 2; }  // utils.rs:75-83
+
+template <typename T>
+__device__ __forceinline__ void load_psi(const Geometry &g, const T *other, const Pixel &p, V4<T> psi[4])
+{
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        psi[n] = (p.active && p.has[n]) ? load4(other + reverse_slot(n) * g.dir_stride + p.nb[n])
+                                        : splat(Real<T>::inf());
+}
+
+template <typename T>
+__device__ __forceinline__ V4<T> load_cost(const uint8_t *cost, const Pixel &p)
+{
+    V4<T> q = splat(T(0));
+    if (p.active) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(cost + p.cost);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q.v[k] = (T)((w >> (8 * k)) & 0xffu);
+    }
+    return q;
+}
+
+// f / |N(t)| as the reference divides (diffusion_graph.rs:249-250); powers of two exactly.
+template <typename T> __device__ __forceinline__ T divide_by_neighbours(T f, int nn)
+{
+    if (nn == 4) return f * T(0.25);
+    if (nn == 2) return f * T(0.5);
+    if (nn == 3) return f / T(3);
+    return f;
+}
+
+// ---- stage 2: one colour's half-sweep ----------------------------------------------
+// grid.y = rows, grid.x = row segments of seg_pixels same-colour pixels; the 4
+// wavefronts of a block take the segment's pixel groups round-robin.
+template <typename T, int LPP>
+__global__ __launch_bounds__(kBlock) void sweep_kernel(Geometry g, T *__restrict__ phi,
+                                                       const uint8_t *__restrict__ cost, T lambda,
+                                                       int colour, int row_begin, int seg_pixels)
+{
+    using R = Real<T>;
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int i = row_begin + blockIdx.y;
+    const int s = (i + colour) & 1;
+    T lam[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
+
+    T *mine = phi + colour * g.colour_stride;
+    const T *other = phi + (1 - colour) * g.colour_stride;
+    const uint8_t *cost_c = cost + colour * g.cost_colour_stride;
+
+    const int seg0 = blockIdx.x * seg_pixels;
+    const int groups = seg_pixels / PPW;  // host guarantees divisibility
+    for (int grp = wave; grp < groups; grp += kBlock / 64) {
+        const int jc = seg0 + grp * PPW + q;
+        const Pixel p = locate(g, i, s, jc, d0);
+        V4<T> psi[4], M[4];
+        load_psi(g, other, p, psi);
+        const V4<T> qc = load_cost<T>(cost_c, p);
+        messages<T, LPP>(psi, lam, lambda, lseg, lane, M);
+        const int K = p.j < g.D - 1 ? p.j : g.D - 1;
+        V4<T> avg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            T acc = T(0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc += p.has[n] ? M[n].v[k] : T(0);
+            avg.v[k] = divide_by_neighbours(qc.v[k] + acc, p.nn);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (p.active && p.has[n]) {
+                V4<T> out;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out.v[k] = (d0 + k <= K) ? avg.v[k] - M[n].v[k] : R::inf();
+                store4(mine + n * g.dir_stride + p.own, out);
+            }
+        }
+    }
+}
+
+// ---- energy and residual ----------------------------------------------------------
+// Per pixel: min_d f_t(d) + sum over slots 2,3 of min_d( phi[t][n][d] + M_n(d) )
+// (diffusion_graph.rs:456-518; min_{d,d'} g evaluated as min_d of phi + M).  Each
+// wavefront writes one partial sum (f64) and one partial max |f_t(d)|.
+template <typename T, int LPP>
+__device__ __forceinline__ T segment_min(T v)
+{
+#pragma unroll
+    for (int m = LPP / 2; m >= 1; m >>= 1) v = Real<T>::min(v, __shfl_xor(v, m));
+    return v;
+}
+
+template <typename T, int LPP>
+__global__ __launch_bounds__(kBlock) void energy_kernel(Geometry g, const T *__restrict__ phi,
+                                                        const uint8_t *__restrict__ cost, T lambda,
+                                                        int colour, int seg_pixels,
+                                                        double *__restrict__ part_sum,
+                                                        double *__restrict__ part_max)
+{
+    using R = Real<T>;
+    constexpr int PPW = 64 / LPP;
+    const T inf = R::inf();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int i = g.row0 + blockIdx.y;
+    const int s = (i + colour) & 1;
+    T lam[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
+    const T *mine = phi + colour * g.colour_stride;
+    const T *other = phi + (1 - colour) * g.colour_stride;
+    const uint8_t *cost_c = cost + colour * g.cost_colour_stride;
+
+    double sum = 0.0, worst = 0.0;
+    const int seg0 = blockIdx.x * seg_pixels;
+    const int groups = seg_pixels / PPW;
+    for (int grp = wave; grp < groups; grp += kBlock / 64) {
+        const int jc = seg0 + grp * PPW + q;
+        const Pixel p = locate(g, i, s, jc, d0);
+        V4<T> psi[4], M[4], own[4];
+        load_psi(g, other, p, psi);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            own[n] = (p.active && p.has[n]) ? load4(mine + n * g.dir_stride + p.own) : splat(T(0));
+        const V4<T> qc = load_cost<T>(cost_c, p);
+        messages<T, LPP>(psi, lam, lambda, lseg, lane, M);
+        const int K = p.j < g.D - 1 ? p.j : g.D - 1;
+        T fmin = inf, e2 = inf, e3 = inf, fabsmax = T(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool valid = p.active && (d0 + k <= K);
+            T sp = T(0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) sp += p.has[n] ? own[n].v[k] : T(0);
+            const T f = qc.v[k] - sp;
+            if (valid) {
+                fmin = R::min(fmin, f);
+                fabsmax = p.nn > 0 ? (R::abs(f) > fabsmax ? R::abs(f) : fabsmax) : fabsmax;
+                e2 = R::min(e2, own[2].v[k] + M[2].v[k]);
+                e3 = R::min(e3, own[3].v[k] + M[3].v[k]);
+            }
+        }
+        fmin = segment_min<T, LPP>(fmin);
+        e2 = segment_min<T, LPP>(e2);
+        e3 = segment_min<T, LPP>(e3);
+        fabsmax = -segment_min<T, LPP>(-fabsmax);
+        if (p.j < g.W && lseg == 0) {
+            double e = (double)fmin;
+            if (p.has[2]) e += (double)e2;
+            if (p.has[3]) e += (double)e3;
+            sum += e;
+            worst = worst > (double)fabsmax ? worst : (double)fabsmax;
+        }
+    }
+    // fixed-order wavefront reduction (lane 0 ends with the total)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        sum += __shfl_down(sum, m);
+        const double o = __shfl_down(worst, m);
+        worst = worst > o ? worst : o;
+    }
+    if (lane == 0) {
+        const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave;
+        part_sum[slot] = sum;
+        part_max[slot] = worst;
+    }
+}
+
+// Deterministic second stage: one block sums / maxes n partials.
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double *__restrict__ part_sum,
+                                                                 const double *__restrict__ part_max,
+                                                                 long long n, double *__restrict__ sum_io,
+                                                                 double *__restrict__ max_io)
+{
+    __shared__ double ssum[kBlock], smax[kBlock];
+    double a = 0.0, b = 0.0;
+    for (long long k = threadIdx.x; k < n; k += kBlock) {
+        a += part_sum[k];
+        b = b > part_max[k] ? b : part_max[k];
+    }
+    ssum[threadIdx.x] = a;
+    smax[threadIdx.x] = b;
+    __syncthreads();
+    for (int m = kBlock / 2; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + m];
+            smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + m] ? smax[threadIdx.x]
+                                                                         : smax[threadIdx.x + m];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *sum_io += ssum[0];
+        *max_io = *max_io > smax[0] ? *max_io : smax[0];
+    }
+}
+
+// ---- stage 3: label extraction -----------------------------------------------------
+// mode 1: argmin_d f_t(d) (diffusion_graph.rs:456-470); mode 0: argmin_d of
+// q_t(d) + sum_n M_n(d) (f_t after the pixel's vertex step, diffusion_graph.rs:302-317).
+// First minimum wins (strict <), i.e. the lexicographic minimum of (value, d).
+template <typename T, int LPP>
+__global__ __launch_bounds__(kBlock) void labels_kernel(Geometry g, const T *__restrict__ phi,
+                                                        const uint8_t *__restrict__ cost, T lambda,
+                                                        int colour, int seg_pixels, int mode,
+                                                        uint32_t *__restrict__ out)
+{
+    using R = Real<T>;
+    constexpr int PPW = 64 / LPP;
+    const T inf = R::inf();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int i = g.row0 + blockIdx.y;
+    const int s = (i + colour) & 1;
+    T lam[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
+    const T *mine = phi + colour * g.colour_stride;
+    const T *other = phi + (1 - colour) * g.colour_stride;
+    const uint8_t *cost_c = cost + colour * g.cost_colour_stride;
+
+    const int seg0 = blockIdx.x * seg_pixels;
+    const int groups = seg_pixels / PPW;
+    for (int grp = wave; grp < groups; grp += kBlock / 64) {
+        const int jc = seg0 + grp * PPW + q;
+        const Pixel p = locate(g, i, s, jc, d0);
+        const V4<T> qc = load_cost<T>(cost_c, p);
+        V4<T> val;
+        if (mode == 0) {
+            V4<T> psi[4], M[4];
+            load_psi(g, other, p, psi);
+            messages<T, LPP>(psi, lam, lambda, lseg, lane, M);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                T acc = T(0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc += p.has[n] ? M[n].v[k] : T(0);
+                val.v[k] = qc.v[k] + acc;
+            }
+        } else {
+            V4<T> own[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                own[n] = (p.active && p.has[n]) ? load4(mine + n * g.dir_stride + p.own) : splat(T(0));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                T sp = T(0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) sp += p.has[n] ? own[n].v[k] : T(0);
+                val.v[k] = qc.v[k] - sp;
+            }
+        }
+        const int K = p.j < g.D - 1 ? p.j : g.D - 1;
+        T best = inf;
+        int arg = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool valid = p.active && (d0 + k <= K);
+            if (valid && val.v[k] < best) { best = val.v[k]; arg = d0 + k; }
+        }
+#pragma unroll
+        for (int m = LPP / 2; m >= 1; m >>= 1) {
+            const T ob = __shfl_xor(best, m);
+            const int oa = __shfl_xor(arg, m);
+            if (ob < best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        // all-infinite column cannot happen (d = 0 is always valid); reference default is 0
+        if (p.j < g.W && lseg == 0)
+            out[(long long)(i - g.row0) * g.W + p.j] = (arg == 0x7fffffff) ? 0u : (uint32_t)arg;
+    }
+}
+
+// ---- stage 1: cost volume --------------------------------------------------------------
+// cost[d][r][j] = |L[i][j] - R[i][j-d]| for d <= j, else 0; r = band row, i = row0 + r.
+// One thread per 4 consecutive bytes of the label-major volume: lanes run along j, so
+// a wavefront writes 256 contiguous bytes.
+__global__ __launch_bounds__(kBlock) void cost_volume_kernel(const uint8_t *__restrict__ L,
+                                                             const uint8_t *__restrict__ Rimg, int W,
+                                                             int D, int row0, int Hb,
+                                                             uint8_t *__restrict__ out)
+{
+    const long long total = (long long)D * Hb * W;
+    const long long base = 4ll * ((long long)blockIdx.x * kBlock + threadIdx.x);
+    if (base >= total) return;
+    uint32_t word = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const long long idx = base + b;
+        if (idx >= total) break;
+        const int j = (int)(idx % W);
+        const long long t = idx / W;
+        const int r = (int)(t % Hb), d = (int)(t / Hb);
+        uint32_t v = 0;
+        if (j >= d) {
+            const long long rowoff = (long long)(row0 + r) * W;
+            const int a = L[rowoff + j], c = Rimg[rowoff + j - d];
+            v = (uint32_t)(a > c ? a - c : c - a);
+        }
+        word |= v << (8 * b);
+    }
+    if (base + 3 < total) {
+        *reinterpret_cast<uint32_t *>(out + base) = word;  // buffer is 4-byte aligned and padded
+    } else {
+        for (int b = 0; base + b < total; ++b) out[base + b] = (uint8_t)(word >> (8 * b));
+    }
+}
+
+// Repack label-major cost[d][r][j] into the sweep's layout packed[colour][r][jc][dp]
+// (dp fastest, 0 for dp >= D) through an LDS transpose: a block takes 64 consecutive
+// columns of one row and all labels.
+constexpr int kPackCols = 64;
+__global__ __launch_bounds__(kBlock) void pack_cost_kernel(Geometry g, const uint8_t *__restrict__ lm,
+                                                           uint8_t *__restrict__ packed)
+{
+    extern __shared__ uint8_t tile[];  // [kPackCols][Dpad + 4]
+    const int pitch = g.Dpad + 4;
+    const int r = blockIdx.y, j0 = blockIdx.x * kPackCols;
+    const int x = threadIdx.x & 63, dy = threadIdx.x >> 6;
+    for (int d = dy; d < g.Dpad; d += kBlock / 64) {
+        uint8_t v = 0;
+        if (d < g.D && j0 + x < g.W) v = lm[((long long)d * g.Hb + r) * g.W + j0 + x];
+        tile[x * pitch + d] = v;
+    }
+    __syncthreads();
+    const int i = g.row0 + r;
+    const int words = g.Dpad / 4;
+    for (int w = threadIdx.x; w < kPackCols * words; w += kBlock) {
+        const int col = w / words, dw = w % words;
+        const int j = j0 + col;
+        if (j >= g.W) continue;
+        const int colour = (i + j) & 1, jc = j >> 1;
+        const uint8_t *src = tile + col * pitch + 4 * dw;
+        const uint32_t word = src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24);
+        *reinterpret_cast<uint32_t *>(packed + colour * g.cost_colour_stride +
+                                      ((long long)r * g.Wh + jc) * g.Dpad + 4 * dw) = word;
+    }
+}
+
+// ---- state initialisation / conversion -----------------------------------------------
+// phi <- 0 on labels d <= j, +inf elsewhere, for every row of the buffer (halo included).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void init_phi_kernel(Geometry g, T *__restrict__ phi)
+{
+    const long long per_plane = (long long)(g.Hb + 2) * g.Wh * g.Dpad;
+    const long long total = 8 * per_plane;
+    const T inf = Real<T>::inf();
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kBlock) {
+        const long long plane = idx / per_plane, rem = idx % per_plane;
+        const int colour = (int)(plane / 4);
+        const int dp = (int)(rem % g.Dpad);
+        const long long px = rem / g.Dpad;
+        const int jc = (int)(px % g.Wh), il = (int)(px / g.Wh);
+        const int i = g.row0 + il - 1;
+        const int j = 2 * jc + ((i + colour) & 1);
+        phi[idx] = (dp < g.D && dp <= j && j < g.W) ? T(0) : inf;
+    }
+}
+
+// Order-independent checksum: sum over valid (existing slot, d <= j) entries of the
+// band's own rows of the entry's bit pattern (as u64, wrapping).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void checksum_kernel(Geometry g, const T *__restrict__ phi,
+                                                          unsigned long long *__restrict__ out)
+{
+    const long long per_plane = (long long)(g.Hb + 2) * g.Wh * g.Dpad;
+    const long long total = 8 * per_plane;
+    unsigned long long acc = 0;
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kBlock) {
+        const long long plane = idx / per_plane, rem = idx % per_plane;
+        const int colour = (int)(plane / 4), n = (int)(plane % 4);
+        const int dp = (int)(rem % g.Dpad);
+        const long long px = rem / g.Dpad;
+        const int jc = (int)(px % g.Wh), il = (int)(px / g.Wh);
+        if (il < 1 || il > g.Hb) continue;
+        const int i = g.row0 + il - 1;
+        const int j = 2 * jc + ((i + colour) & 1);
+        if (j >= g.W || dp >= g.D || dp > j) continue;
+        const bool has = n == 0 ? j > 0 : n == 1 ? i > 0 : n == 2 ? j + 1 < g.W : i + 1 < g.H;
+        if (!has) continue;
+        T v = phi[idx];
+        if (v == T(0)) v = T(0);  // -0 and +0 count alike
+        if constexpr (sizeof(T) == 4) acc += (unsigned long long)__builtin_bit_cast(uint32_t, v);
+        else acc += __builtin_bit_cast(unsigned long long, v);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_down(acc, m);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+}  // namespace ds

@@ -1,0 +1,196 @@
+"""ctypes binding of the C ABI in include/diffstereo.h (tests and benchmark use it).
+
+There is no CPU fallback: if csrc/libdiffstereo.so is missing, or a declared symbol
+is not exported, `lib()` raises.  `DiffusionGraph` keeps the reference's names where
+one exists (diffusion_stereo/src/diffusion_graph.rs:39-539).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libdiffstereo.so")
+DS_F32, DS_F64 = 0, 1
+_DTYPES = {"f32": (DS_F32, np.float32), "f64": (DS_F64, np.float64)}
+
+_P, _I, _D = C.c_void_p, C.c_int, C.c_double
+_PP = C.POINTER(C.c_void_p)
+_IP, _DP = C.POINTER(C.c_int), C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); must list every symbol include/diffstereo.h declares
+SYMBOLS = {
+    "ds_create": (_I, [_P, _P, _I, _I, _I, _D, _I, _PP]),
+    "ds_create_band": (_I, [_P, _P, _I, _I, _I, _D, _I, _I, _I, _I, _PP]),
+    "ds_destroy": (None, [_P]),
+    "ds_last_error": (C.c_char_p, [_P]),
+    "ds_set_stream": (_I, [_P, _P]),
+    "ds_synchronize": (_I, [_P]),
+    "ds_build_cost": (_I, [_P]),
+    "ds_get_cost": (_I, [_P, _P]),
+    "ds_iterate": (_I, [_P, _I]),
+    "ds_sweep": (_I, [_P, _I, _I, _I]),
+    "ds_energy": (_I, [_P, _DP, _DP]),
+    "ds_labels": (_I, [_P, _I, _P]),
+    "ds_get_phi_rows": (_I, [_P, _I, _I, _P]),
+    "ds_set_phi_rows": (_I, [_P, _I, _I, _P]),
+    "ds_get_phi": (_I, [_P, _P]),
+    "ds_set_phi": (_I, [_P, _P]),
+    "ds_halo": (_I, [_P, _I, _I, _I, _PP, C.POINTER(C.c_size_t)]),
+    "ds_profile_begin": (_I, [_P, _I]),
+    "ds_profile_end": (_I, [_P, _IP, _DP, _DP, _DP]),
+    "ds_info": (_I, [_P, _IP, _IP, _IP, _IP, _IP, _IP]),
+    "ds_checksum": (_I, [_P, C.POINTER(C.c_uint64)]),
+}
+
+_LIB = None
+
+
+class DiffStereoError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("diffstereo error %d: %s" % (code, text))
+        self.code = code
+
+
+def lib():
+    """dlopen the library and bind every declared symbol (raises if one is missing)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("HIP library not built: %s (run __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DiffusionGraph:
+    """Device-resident DiffusionGraph (the whole image, or one row band of it)."""
+
+    def __init__(self, left_image, right_image, max_disparity, smoothing_term, dtype="f32",
+                 row_begin=None, row_end=None, device=-1):
+        self._h = None
+        left = np.ascontiguousarray(left_image, dtype=np.uint8)
+        right = np.ascontiguousarray(right_image, dtype=np.uint8)
+        if left.ndim != 2 or left.shape != right.shape:
+            raise ValueError("left and right images must be 2-D and of equal shape")
+        self.H, self.W = left.shape
+        self.D = int(max_disparity)
+        self.dtype = dtype
+        self._code, self._np = _DTYPES[dtype]
+        self.row_begin = 0 if row_begin is None else int(row_begin)
+        self.row_end = self.H if row_end is None else int(row_end)
+        h = C.c_void_p()
+        rc = lib().ds_create_band(_ptr(left), _ptr(right), self.H, self.W, self.D,
+                                  float(smoothing_term), self._code, self.row_begin, self.row_end,
+                                  int(device), C.byref(h))
+        if rc != 0:
+            raise DiffStereoError(rc, (lib().ds_last_error(None) or b"").decode())
+        self._h = h
+        self.rows = self.row_end - self.row_begin
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DiffStereoError(rc, (lib().ds_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h is not None:
+            lib().ds_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        self._chk(lib().ds_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        self._chk(lib().ds_synchronize(self._h))
+
+    def build_cost(self):
+        self._chk(lib().ds_build_cost(self._h))
+
+    def get_cost(self):
+        out = np.empty((self.D, self.rows, self.W), dtype=np.uint8)
+        self._chk(lib().ds_get_cost(self._h, _ptr(out)))
+        return out
+
+    def iterate(self, n_iters):
+        """n_iters x diffusion_act (diffusion_graph.rs:264-293) under the red-black schedule."""
+        self._chk(lib().ds_iterate(self._h, int(n_iters)))
+
+    def sweep(self, colour, row_begin=None, row_end=None):
+        self._chk(lib().ds_sweep(self._h, int(colour),
+                                 self.row_begin if row_begin is None else int(row_begin),
+                                 self.row_end if row_end is None else int(row_end)))
+
+    def energy(self, with_residual=False):
+        e, r = C.c_double(), C.c_double()
+        self._chk(lib().ds_energy(self._h, C.byref(e), C.byref(r)))
+        return (e.value, r.value) if with_residual else e.value
+
+    def labels(self, mode=0):
+        out = np.empty((self.rows, self.W), dtype=np.uint32)
+        self._chk(lib().ds_labels(self._h, int(mode), _ptr(out)))
+        return out
+
+    def get_phi(self, row_begin=None, row_end=None):
+        rb = self.row_begin if row_begin is None else int(row_begin)
+        re = self.row_end if row_end is None else int(row_end)
+        out = np.empty((re - rb, self.W, 4, self.D), dtype=self._np)
+        self._chk(lib().ds_get_phi_rows(self._h, rb, re, _ptr(out)))
+        return out
+
+    def set_phi(self, phi, row_begin=None, row_end=None):
+        rb = self.row_begin if row_begin is None else int(row_begin)
+        re = self.row_end if row_end is None else int(row_end)
+        phi = np.ascontiguousarray(phi, dtype=self._np)
+        if phi.shape != (re - rb, self.W, 4, self.D):
+            raise ValueError("phi must have shape [rows][W][4][D]")
+        self._chk(lib().ds_set_phi_rows(self._h, rb, re, _ptr(phi)))
+
+    def halo(self, colour, side, which):
+        """(device pointer, bytes) of a halo row; side 0=top 1=bottom, which 0=send 1=recv."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(lib().ds_halo(self._h, colour, side, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def profile_begin(self, max_launches):
+        self._chk(lib().ds_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        n, tot, lo, hi = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        self._chk(lib().ds_profile_end(self._h, C.byref(n), C.byref(tot), C.byref(lo), C.byref(hi)))
+        return {"launches": n.value, "total_ms": tot.value, "min_ms": lo.value, "max_ms": hi.value}
+
+    def checksum(self):
+        v = C.c_uint64()
+        self._chk(lib().ds_checksum(self._h, C.byref(v)))
+        return v.value
+
+
+def host_checksum(phi, row_begin, H, W, D):
+    """The same order-independent checksum as ds_checksum, from a host array
+    phi[rows][W][4][D] holding image rows [row_begin, row_begin + rows)."""
+    phi = np.ascontiguousarray(phi)
+    rows = phi.shape[0]
+    ii = (np.arange(rows) + row_begin)[:, None, None, None]
+    jj = np.arange(W)[None, :, None, None]
+    dd = np.arange(D)[None, None, None, :]
+    has = np.stack([np.broadcast_to(jj > 0, (rows, W, 1, 1)), np.broadcast_to(ii > 0, (rows, W, 1, 1)),
+                    np.broadcast_to(jj + 1 < W, (rows, W, 1, 1)),
+                    np.broadcast_to(ii + 1 < H, (rows, W, 1, 1))], axis=2).reshape(rows, W, 4, 1)
+    mask = has & (dd <= jj)
+    vals = np.where(phi == 0, 0, phi).astype(phi.dtype)  # -0 -> +0
+    bits = vals.view(np.uint32 if phi.dtype == np.float32 else np.uint64).astype(np.uint64)
+    return int(np.sum(np.where(mask, bits, np.uint64(0)), dtype=np.uint64))
