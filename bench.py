@@ -1,0 +1,183 @@
+"""Benchmark of the diffusion sweep (the hot path of diffusion_stereo) on MI355X.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one diffusion iteration (red half-sweep + black half-sweep over the whole
+image) of the synthetic 3840x2160 pair with 256 disparity labels, f32 potentials,
+cost volume resident in HBM.  For N > 1 the image is split into N row bands, one rank
+per GPU, with one halo row exchanged per neighbour after each colour (RCCL
+send/recv): total work is fixed, so scaling is strong.
+
+Prints ONE JSON line on rank 0: metric = valid (pixel, label) pairs x iterations per
+second for the whole job, plus `roofline` (sweep kernel against the 8 TB/s HBM peak,
+from HIP events around every launch in the timed region) and `cpu_baseline` (the
+faithful single-threaded CPU restatement of the reference rule, timed on this host on
+a bounded crop of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from stereo_vision_amd import bands, diffstereo, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+WORKLOADS = {
+    "4k_256": dict(H=2160, W=3840, D=256, dtype="f32"),
+    "1080p_128": dict(H=1080, W=1920, D=128, dtype="f32"),
+    "8k_256_f64": dict(H=4320, W=7680, D=256, dtype="f64"),
+}
+
+
+def valid_pairs(H, W, D):
+    """(pixel, label) pairs with d <= j (the ones the reference touches)."""
+    return H * sum(min(j, D - 1) + 1 for j in range(W))
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per sweep launch from the committed rocprofv3 --pmc passes
+    (profiles/pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs,
+    FETCH_SIZE doubled as gfx950 requires); None if no pass matches this kernel."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))[workload]
+        return float(rec["hbm_bytes_per_launch"]) if rec["kernel"] == kernel else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpu_baseline(left, right, D, lam, budget_s=12.0):
+    """Faithful O(D^2) single-thread restatement (reference rule, raster order) on a crop."""
+    from oracle import pyoracle
+    H, W = 4, min(left.shape[1], 384)
+    crop_l, crop_r = left[:H, :W], right[:H, :W]
+    g = pyoracle.OracleGraph(crop_l, crop_r, D, lam)
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        g.diffusion_act()
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or iters >= 50:
+            break
+    pl = valid_pairs(H, W, D)
+    out = {"value": pl * iters / dt / 1e9, "unit": "G pixel*label*iters/s", "cores": 1, "kind": "port",
+           "sample": "C restatement of diffusion_act (raster order, O(D^2), f64), %d iteration(s) on the "
+                     "%dx%d top-left crop of the same synthetic pair, D=%d, %.1f s" % (iters, W, H, D, dt)}
+    # the O(D) OpenMP port of the checkerboard sweep, all host threads OpenMP gives us
+    Hf = min(left.shape[0], 96)
+    f = pyoracle.FastOracle(left[:Hf], right[:Hf], D, lam, dtype="f32")
+    f.iterate(1)
+    t0 = time.perf_counter()
+    f.iterate(2)
+    dt = time.perf_counter() - t0
+    out["fast_port"] = {"value": valid_pairs(Hf, left.shape[1], D) * 2 / dt / 1e9,
+                        "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+                        "sample": "O(D) OpenMP checkerboard port, f32, 2 iterations on the top %d rows" % Hf}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="4k_256", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    H, W, D, dtype, lam = wl["H"], wl["W"], wl["D"], wl["dtype"], 1.2
+    left, right, _ = synth.synthetic_pair(H, W, D)
+    rb, re = bands.partition_rows(H, world)[rank]
+    graph = diffstereo.DiffusionGraph(left, right, D, lam, dtype=dtype, row_begin=rb, row_end=re,
+                                      device=local_rank)
+    engine = bands.HipBandEngine(graph)
+    runner = bands.BandRunner(engine, rank=rank, world=world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    runner.iterate(args.warmup)
+    fence()
+    launches_per_step = 2 if world == 1 else 6
+    graph.profile_begin(args.steps * launches_per_step)
+    t0 = time.perf_counter()
+    runner.iterate(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = graph.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    energy = runner.energy()
+
+    if rank == 0:
+        pl = valid_pairs(H, W, D)
+        elem = 4 if dtype == "f32" else 8
+        bytes_per_pl = 8 * elem + 1  # each phi row read once + written once, u8 cost read once
+        my_pl = valid_pairs(re - rb, W, D)
+        kernel_s = prof["total_ms"] / 1e3
+        achieved = bytes_per_pl * my_pl * args.steps / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        kernel = "ds::sweep_kernel<%s, %d>" % ("float" if dtype == "f32" else "double",
+                                               16 if D <= 64 else 32 if D <= 128 else 64)
+        avg_launch_s = kernel_s / max(prof["launches"], 1)
+        pmc_bytes = pmc_traffic(args.workload, kernel) if world == 1 else None
+        line = {
+            "metric": "G pixel*label*iters/s (node), 4Kx256 disparities",
+            "value": pl * args.steps / elapsed / 1e9,
+            "unit": "G pixel*label*iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d stereo pair, %d disparities, lambda=1.2, %s phi, "
+                                   "u8 cost volume in HBM, red-black diffusion iterations" % (W, H, D, dtype),
+                       "valid_pixel_labels": pl, "row_bands": world,
+                       "halo_exchange": "none" if world == 1 else "RCCL send/recv, 1 row per neighbour per colour"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_bytes / avg_launch_s / 1e9 if pmc_bytes and avg_launch_s > 0 else None,
+                         "traffic_bytes_per_launch": pmc_bytes,
+                         "kernel": kernel,
+                         "algorithmic_bytes_per_pixel_label": bytes_per_pl,
+                         "launches": prof["launches"],
+                         "avg_launch_ms": prof["total_ms"] / max(prof["launches"], 1),
+                         "rank": 0},
+            "energy": energy,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(left, right, D, lam)
+        print(json.dumps(line), flush=True)
+
+    graph.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

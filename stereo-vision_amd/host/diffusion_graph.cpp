@@ -1,0 +1,270 @@
+#include "diffusion_graph.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+
+#include "pgm.hpp"
+
+namespace stereo {
+
+void DiffusionGraph::check(int rc) const
+{
+    if (rc != DS_OK) throw std::runtime_error(std::string("diffstereo: ") + ds_last_error(h_));
+}
+
+DiffusionGraph DiffusionGraph::initialize(const std::vector<std::vector<std::uint32_t>> &left_image,
+                                          const std::vector<std::vector<std::uint32_t>> &right_image,
+                                          std::size_t max_disparity, double smoothing_term, int dtype)
+{
+    if (left_image.empty() || left_image.size() != right_image.size() ||
+        left_image[0].size() != right_image[0].size())
+        throw std::invalid_argument("left and right images must have the same non-empty shape");
+    DiffusionGraph g;
+    g.H_ = left_image.size();
+    g.W_ = left_image[0].size();
+    g.max_disparity = max_disparity;
+    g.smoothing_term = smoothing_term;
+    g.left_image = left_image;
+    g.right_image = right_image;
+    g.dtype_ = dtype;
+    std::vector<std::uint8_t> l(g.H_ * g.W_), r(g.H_ * g.W_);
+    for (std::size_t i = 0; i < g.H_; ++i) {
+        if (left_image[i].size() != g.W_ || right_image[i].size() != g.W_)
+            throw std::invalid_argument("ragged image");
+        for (std::size_t j = 0; j < g.W_; ++j) {
+            if (left_image[i][j] > 255 || right_image[i][j] > 255)
+                throw std::invalid_argument("intensities must be in 0..255");  // table is 256 x 256 (:71-76)
+            l[i * g.W_ + j] = static_cast<std::uint8_t>(left_image[i][j]);
+            r[i * g.W_ + j] = static_cast<std::uint8_t>(right_image[i][j]);
+        }
+    }
+    int rc = ds_create(l.data(), r.data(), (int)g.H_, (int)g.W_, (int)max_disparity, smoothing_term, dtype,
+                       &g.h_);
+    if (rc != DS_OK) throw std::runtime_error(std::string("diffstereo: ") + ds_last_error(nullptr));
+    return g;
+}
+
+DiffusionGraph::DiffusionGraph(DiffusionGraph &&o) noexcept { *this = std::move(o); }
+
+DiffusionGraph &DiffusionGraph::operator=(DiffusionGraph &&o) noexcept
+{
+    if (this != &o) {
+        ds_destroy(h_);
+        h_ = o.h_;
+        o.h_ = nullptr;
+        max_disparity = o.max_disparity;
+        smoothing_term = o.smoothing_term;
+        left_image = std::move(o.left_image);
+        right_image = std::move(o.right_image);
+        dtype_ = o.dtype_;
+        H_ = o.H_;
+        W_ = o.W_;
+        phi_ = std::move(o.phi_);
+        host_valid_ = o.host_valid_;
+        host_dirty_ = o.host_dirty_;
+    }
+    return *this;
+}
+
+DiffusionGraph::~DiffusionGraph() { ds_destroy(h_); }
+
+void DiffusionGraph::pull()
+{
+    if (host_valid_) return;
+    const std::size_t n = H_ * W_ * 4 * max_disparity;
+    phi_.resize(n);
+    if (dtype_ == DS_F64) {
+        check(ds_get_phi(h_, phi_.data()));
+    } else {
+        std::vector<float> tmp(n);
+        check(ds_get_phi(h_, tmp.data()));
+        for (std::size_t k = 0; k < n; ++k) phi_[k] = tmp[k];
+    }
+    host_valid_ = true;
+    host_dirty_ = false;
+}
+
+void DiffusionGraph::push()
+{
+    if (!host_dirty_) return;
+    if (dtype_ == DS_F64) {
+        check(ds_set_phi(h_, phi_.data()));
+    } else {
+        std::vector<float> tmp(phi_.begin(), phi_.end());
+        check(ds_set_phi(h_, tmp.data()));
+    }
+    host_dirty_ = false;
+}
+
+double DiffusionGraph::potential(std::size_t i, std::size_t j, std::size_t n, std::size_t d)
+{
+    pull();
+    return phi_.at(idx(i, j, n, d));
+}
+
+void DiffusionGraph::set_potential(std::size_t i, std::size_t j, std::size_t n, std::size_t d, double v)
+{
+    pull();
+    phi_.at(idx(i, j, n, d)) = v;
+    host_dirty_ = true;
+}
+
+double DiffusionGraph::sum_of_potentials(std::size_t i, std::size_t j, std::size_t d)
+{
+    pull();
+    double s = 0.;
+    for (std::size_t n = 0; n < 4; ++n)
+        if (neighbor_exists(i, j, n, H_, W_)) s += phi_[idx(i, j, n, d)];
+    return s;
+}
+
+double DiffusionGraph::vertex_penalty_with_potentials(std::size_t i, std::size_t j, std::size_t d)
+{
+    return q(i, j, d) - sum_of_potentials(i, j, d);
+}
+
+double DiffusionGraph::edge_penalty_with_potential(std::size_t i, std::size_t j, std::size_t n, std::size_t d,
+                                                   std::size_t n_d)
+{
+    pull();
+    auto [n_i, n_j, n_index] = neighbor_index(i, j, n);
+    const double dist = d > n_d ? double(d - n_d) : double(n_d - d);
+    return smoothing_term * dist + phi_[idx(i, j, n, d)] + phi_[idx(n_i, n_j, n_index, n_d)];
+}
+
+bool DiffusionGraph::edge_exists(std::size_t i, std::size_t j, std::size_t n, std::size_t d,
+                                 std::size_t n_d) const
+{
+    if (!neighbor_exists(i, j, n, H_, W_)) return false;
+    const std::size_t n_j = n == 0 ? j - 1 : n == 2 ? j + 1 : j;
+    if (j >= d && n_j >= n_d) {
+        if (n == 2 && n_d > d + 1) return false;
+        if (n == 0 && d > n_d + 1) return false;
+        return true;
+    }
+    return false;
+}
+
+double DiffusionGraph::penalty(const Matrix &disparity_map)
+{
+    const double inf = std::numeric_limits<double>::infinity();
+    double p = 0.;
+    for (std::size_t i = 0; i < H_; ++i)
+        for (std::size_t j = 0; j < W_; ++j) {
+            const std::size_t d = disparity_map[i][j];
+            if (j >= d) {
+                p += vertex_penalty_with_potentials(i, j, d);
+                for (std::size_t n = 2; n < 4; ++n)
+                    if (neighbor_exists(i, j, n, H_, W_)) {
+                        auto [n_i, n_j, n_index] = neighbor_index(i, j, n);
+                        (void)n_index;
+                        const std::size_t nd = disparity_map[n_i][n_j];
+                        p += edge_exists(i, j, n, d, nd) ? edge_penalty_with_potential(i, j, n, d, nd) : inf;
+                    }
+            } else {
+                p += inf;
+            }
+        }
+    return p;
+}
+
+double DiffusionGraph::min_edge_between_neighbors(std::size_t i, std::size_t j, std::size_t n, std::size_t d)
+{
+    double m = std::numeric_limits<double>::infinity();
+    for (std::size_t n_d = 0; n_d < max_disparity; ++n_d)
+        if (edge_exists(i, j, n, d, n_d)) {
+            const double e = edge_penalty_with_potential(i, j, n, d, n_d);
+            if (e < m) m = e;
+        }
+    return m;
+}
+
+std::pair<std::size_t, double> DiffusionGraph::min_penalty_vertex(std::size_t i, std::size_t j)
+{
+    double m = std::numeric_limits<double>::infinity();
+    std::size_t disparity = 0;
+    for (std::size_t d = 0; d < max_disparity; ++d)
+        if (j >= d) {
+            const double v = vertex_penalty_with_potentials(i, j, d);
+            if (v < m) { disparity = d; m = v; }
+        }
+    return {disparity, m};
+}
+
+double DiffusionGraph::min_penalty_edge(std::size_t i, std::size_t j, std::size_t n)
+{
+    double m = std::numeric_limits<double>::infinity();
+    for (std::size_t d = 0; d < max_disparity; ++d)
+        for (std::size_t n_d = 0; n_d < max_disparity; ++n_d)
+            if (edge_exists(i, j, n, d, n_d)) {
+                const double e = edge_penalty_with_potential(i, j, n, d, n_d);
+                if (e < m) m = e;
+            }
+    return m;
+}
+
+void DiffusionGraph::diffusion_act()
+{
+    push();
+    check(ds_iterate(h_, 1));
+    host_valid_ = false;
+}
+
+void DiffusionGraph::diffusion(std::size_t first_iteration, std::size_t number_of_iterations, bool verbose)
+{
+    // Same observable behaviour as the reference: the energy before the first and after
+    // every iteration on stdout, per-iteration wall time appended to elapsed_time.txt.
+    std::ofstream file("elapsed_time.txt");
+    if (!file) throw std::runtime_error("cannot create elapsed_time.txt");
+    push();
+    if (verbose) std::printf("Energy: %.17g\n", energy());
+    for (std::size_t i = first_iteration; i < first_iteration + number_of_iterations; ++i) {
+        if (verbose) std::printf("Iteration # %zu\n", i);
+        const auto t0 = std::chrono::steady_clock::now();
+        check(ds_iterate(h_, 1));
+        const std::chrono::duration<double> dt = std::chrono::steady_clock::now() - t0;
+        file << dt.count() << "s";
+        if (verbose) std::printf("Energy: %.17g\n", energy());
+    }
+    host_valid_ = false;
+}
+
+double DiffusionGraph::energy()
+{
+    push();
+    double e = 0.;
+    check(ds_energy(h_, &e, nullptr));
+    return e;
+}
+
+static Matrix labels_to_matrix(const std::vector<std::uint32_t> &lab, std::size_t H, std::size_t W)
+{
+    Matrix m(H, std::vector<std::size_t>(W));
+    for (std::size_t i = 0; i < H; ++i)
+        for (std::size_t j = 0; j < W; ++j) m[i][j] = lab[i * W + j];
+    return m;
+}
+
+Matrix DiffusionGraph::depth_map()
+{
+    push();
+    std::vector<std::uint32_t> lab(H_ * W_);
+    check(ds_labels(h_, 1, lab.data()));
+    return labels_to_matrix(lab, H_, W_);
+}
+
+Matrix DiffusionGraph::belief_depth_map()
+{
+    push();
+    std::vector<std::uint32_t> lab(H_ * W_);
+    check(ds_labels(h_, 0, lab.data()));
+    return labels_to_matrix(lab, H_, W_);
+}
+
+void DiffusionGraph::build_depth_map(std::size_t iteration)
+{
+    pgm_writer(depth_map(), "./images/results/result_" + std::to_string(iteration) + ".pgm", max_disparity);
+}
+
+}  // namespace stereo

@@ -1,0 +1,86 @@
+// Host-side DiffusionGraph: the reference's public interface
+// (diffusion_stereo/src/diffusion_graph.rs:39-539) over the device library.
+//
+// State lives on the GPU (include/diffstereo.h).  The sweeps, the energy and the
+// per-pixel argmin run there; the fine-grained accessors the crossing-out code needs
+// (vertex / edge penalties for one (i, j, n, d)) are evaluated on a host copy of phi
+// that is fetched lazily and dropped whenever the device state changes.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "diffstereo.h"
+#include "utils.hpp"
+
+namespace stereo {
+
+class DiffusionGraph {
+public:
+    // diffusion_graph.rs:65-88.  Images hold 0..255; 1 <= max_disparity <= 256.
+    // dtype: DS_F64 (the reference's precision) or DS_F32.
+    static DiffusionGraph initialize(const std::vector<std::vector<std::uint32_t>> &left_image,
+                                     const std::vector<std::vector<std::uint32_t>> &right_image,
+                                     std::size_t max_disparity, double smoothing_term, int dtype = DS_F64);
+    DiffusionGraph(DiffusionGraph &&o) noexcept;
+    DiffusionGraph &operator=(DiffusionGraph &&o) noexcept;
+    DiffusionGraph(const DiffusionGraph &) = delete;
+    DiffusionGraph &operator=(const DiffusionGraph &) = delete;
+    ~DiffusionGraph();
+
+    std::size_t height() const { return H_; }
+    std::size_t width() const { return W_; }
+    std::size_t max_disparity;   // public fields of the reference struct
+    double smoothing_term;
+    std::vector<std::vector<std::uint32_t>> left_image, right_image;
+
+    // potentials[i][j][n][d] (diffusion_graph.rs:43): read / write through the host copy
+    double potential(std::size_t i, std::size_t j, std::size_t n, std::size_t d);
+    void set_potential(std::size_t i, std::size_t j, std::size_t n, std::size_t d, double v);
+
+    double sum_of_potentials(std::size_t i, std::size_t j, std::size_t d);                 // :99-107
+    double vertex_penalty_with_potentials(std::size_t i, std::size_t j, std::size_t d);    // :118-122
+    double edge_penalty_with_potential(std::size_t i, std::size_t j, std::size_t n, std::size_t d,
+                                       std::size_t n_d);                                   // :135-141
+    bool edge_exists(std::size_t i, std::size_t j, std::size_t n, std::size_t d, std::size_t n_d) const;  // :152-169
+    double penalty(const Matrix &disparity_map);                                           // :177-201
+    double min_edge_between_neighbors(std::size_t i, std::size_t j, std::size_t n, std::size_t d);  // :212-224
+    std::pair<std::size_t, double> min_penalty_vertex(std::size_t i, std::size_t j);       // :456-470
+    double min_penalty_edge(std::size_t i, std::size_t j, std::size_t n);                  // :480-494
+
+    // Device operations.
+    void diffusion_act();                                                   // :264-293, red-black order
+    void diffusion(std::size_t first_iteration, std::size_t number_of_iterations,
+                   bool verbose = true);                                    // :349-368
+    double energy();                                                        // :502-518
+    Matrix depth_map();          // :376-390 without the file write: argmin_d f_t(d)
+    Matrix belief_depth_map();   // argmin_d of f_t after the pixel's vertex step (:302-317)
+    void build_depth_map(std::size_t iteration);                            // :376-390
+
+private:
+    DiffusionGraph() = default;
+    void check(int rc) const;
+    void pull();   // device -> host copy of phi, if stale
+    void push();   // host copy -> device, if modified
+    std::size_t idx(std::size_t i, std::size_t j, std::size_t n, std::size_t d) const
+    {
+        return ((i * W_ + j) * 4 + n) * max_disparity + d;
+    }
+    double q(std::size_t i, std::size_t j, std::size_t d) const
+    {
+        const double a = left_image[i][j], b = right_image[i][j - d];
+        return a > b ? a - b : b - a;
+    }
+
+    ds_handle *h_ = nullptr;
+    int dtype_ = DS_F64;
+    std::size_t H_ = 0, W_ = 0;
+    std::vector<double> phi_;  // host copy, reference layout
+    bool host_valid_ = false, host_dirty_ = false;
+};
+
+}  // namespace stereo

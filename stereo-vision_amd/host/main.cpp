@@ -1,0 +1,85 @@
+// stereovision: left/right ASCII PGM in, disparity PGM out -- the CLI contract of the
+// reference's main (diffusion_stereo/src/main.rs:36-98), with its hard-coded constants
+// as defaults: max disparity 40, smoothing 1.2, epsilon 1/(10*W*H), batches of 200.
+//
+//   stereovision LEFT.pgm RIGHT.pgm OUT.pgm [--max-disparity N] [--smoothing X]
+//                [--epsilon E] [--batch B] [--max-batches M] [--dtype f64|f32]
+//                [--decode crossing|belief] [--iterations K] [--quiet]
+//
+// --decode crossing (default) is the reference pipeline: diffusion batches on the GPU
+// until the epsilon-consistent sub-graph is non-empty, then the smallest surviving
+// label per pixel (host masks: small images only).  --decode belief runs --iterations
+// diffusion iterations and takes the per-pixel argmin on the GPU (any size).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "crossing_out_graph.hpp"
+#include "diffusion_graph.hpp"
+#include "pgm.hpp"
+
+int main(int argc, char **argv)
+{
+    using namespace stereo;
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: %s LEFT.pgm RIGHT.pgm OUT.pgm [options]\n", argv[0]);
+        return 2;
+    }
+    const std::string left_path = argv[1], right_path = argv[2], out_path = argv[3];
+    std::size_t max_disparity = 40, batch = 200, max_batches = 1000, iterations = 200;
+    double smoothing = 1.2, epsilon = -1.;
+    int dtype = DS_F64;
+    bool crossing = true, verbose = true;
+    for (int a = 4; a < argc; ++a) {
+        const std::string o = argv[a];
+        auto need = [&](const char *name) -> const char * {
+            if (a + 1 >= argc) {
+                std::fprintf(stderr, "%s needs a value\n", name);
+                std::exit(2);
+            }
+            return argv[++a];
+        };
+        if (o == "--max-disparity") max_disparity = std::strtoul(need("--max-disparity"), nullptr, 10);
+        else if (o == "--smoothing") smoothing = std::strtod(need("--smoothing"), nullptr);
+        else if (o == "--epsilon") epsilon = std::strtod(need("--epsilon"), nullptr);
+        else if (o == "--batch") batch = std::strtoul(need("--batch"), nullptr, 10);
+        else if (o == "--max-batches") max_batches = std::strtoul(need("--max-batches"), nullptr, 10);
+        else if (o == "--iterations") iterations = std::strtoul(need("--iterations"), nullptr, 10);
+        else if (o == "--dtype") dtype = std::strcmp(need("--dtype"), "f32") == 0 ? DS_F32 : DS_F64;
+        else if (o == "--decode") crossing = std::strcmp(need("--decode"), "belief") != 0;
+        else if (o == "--quiet") verbose = false;
+        else {
+            std::fprintf(stderr, "unknown option %s\n", o.c_str());
+            return 2;
+        }
+    }
+    try {
+        const PgmImage right = pgm_reader(right_path);
+        const PgmImage left = pgm_reader(left_path);
+        if (right.width != left.width || right.height != left.height)
+            throw std::runtime_error("left and right images differ in size");
+        if (epsilon < 0.) epsilon = 1. / double(10 * left.width * left.height);
+        std::printf("Epsilon: %g\n", epsilon);
+        DiffusionGraph graph = DiffusionGraph::initialize(left.matrix, right.matrix, max_disparity, smoothing, dtype);
+        Matrix disparity_map;
+        if (crossing) {
+            CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph));
+            cog.diffusion_while_not_consistent(epsilon, batch, max_batches, verbose);
+            std::printf("Finding disparity map ...\n");
+            disparity_map = cog.simple_best_labeling();
+        } else {
+            graph.diffusion(1, iterations, verbose);
+            std::printf("Finding disparity map ...\n");
+            disparity_map = graph.belief_depth_map();
+        }
+        std::printf("Disparity map is consistent: %s\n", check_disparity_map(disparity_map) ? "true" : "false");
+        pgm_writer(disparity_map, out_path, max_disparity);
+        std::printf("Disparity map is saved to `%s`\n", out_path.c_str());
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,59 @@
+"""The C++ host (stereo-vision_amd/host) on a GPU: known answers of the reference's
+unit tests through the host classes, and the CLI contract (left/right PGM in, disparity
+PGM out, diffusion_stereo/src/main.rs:36-98) on the reference's bundled pair."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import PKG_DIR
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+HOST = os.path.join(PKG_DIR, "host")
+
+
+def test_host_known_answers():
+    out = subprocess.run([os.path.join(HOST, "kat_host")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host KATs ok" in out.stdout
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_cli_reference_pipeline_on_bundled_pair(tmp_path, golden_dir, dtype):
+    """main's pipeline with its own constants (D = 40, lambda = 1.2, eps = 1/(10WH), batch
+    200): GPU checkerboard diffusion + host crossing-out must give the disparity map the
+    sequential CPU restatement of the reference gives (25/25 pixels)."""
+    gold = np.load(os.path.join(golden_dir, "bundled_main.npz"))
+    out_pgm = tmp_path / "best_labeling.pgm"
+    run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
+                          os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--dtype", dtype, "--quiet"],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Disparity map is consistent: true" in run.stdout
+    m, w, h = pyoracle.pgm_reader(str(out_pgm))
+    assert (w, h) == (5, 5)
+    assert open(out_pgm).read().splitlines()[2] == "40"  # maxval = max_disparity (main.rs:69-71)
+    assert np.array_equal(m.astype(np.int32), gold["labels_seq"])
+    assert float(np.mean(m.astype(np.int32) == gold["labels_seq"])) >= 0.995
+
+
+def test_cli_belief_decode(tmp_path, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "bundled_seq_100.npz"))
+    out_pgm = tmp_path / "belief.pgm"
+    run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
+                          os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--decode", "belief",
+                          "--iterations", "100", "--quiet"],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stdout + run.stderr
+    m, _, _ = pyoracle.pgm_reader(str(out_pgm))
+    assert np.array_equal(m.astype(np.int32), gold["belief_labels"])
+
+
+def test_cli_rejects_bad_input(tmp_path, golden_dir):
+    bad = tmp_path / "bad.pgm"
+    bad.write_text("P2\n3 2\n255\n1 2 3\n4 5\n")
+    run = subprocess.run([os.path.join(HOST, "stereovision"), str(bad), str(bad), str(tmp_path / "o.pgm")],
+                         capture_output=True, text=True, timeout=60, cwd=str(tmp_path))
+    assert run.returncode == 1 and "pixel count" in run.stderr
