@@ -66,7 +66,8 @@ void ds_destroy(ds_handle *h);
 /* Text of the last error on this handle (or of the last failed ds_create* when h is NULL). */
 const char *ds_last_error(const ds_handle *h);
 
-/* Run all work of this handle on the given hipStream_t (NULL = the handle's own stream). */
+/* Run all further work of this handle on the given hipStream_t instead of the handle's own
+ * stream (NULL = the device's default stream).  Pending work is waited for first. */
 int ds_set_stream(ds_handle *h, void *hip_stream);
 
 /* Waits until all work queued by this handle has finished. */

@@ -109,7 +109,7 @@ void release(ds_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     (void)hipFree(h->d_left);
     (void)hipFree(h->d_right);
@@ -363,7 +363,7 @@ int ds_set_stream(ds_handle *h, void *hip_stream)
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    h->stream = static_cast<hipStream_t>(hip_stream);
     return DS_OK;
 }
 

@@ -1,0 +1,68 @@
+"""Rehearsal of the multi-rank path on ONE GPU: two or three ranks (processes) share
+cuda:0, each owns a row band through the C ABI, and the halo rows travel rank to rank
+over gloo (staged through the host, since RCCL refuses two ranks on one device).  It
+exercises exactly the code the N-GPU benchmark runs (bands.BandRunner + HipBandEngine,
+ds_sweep on row ranges, ds_halo device views, torch streams) except the RCCL transport."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from tests.util import random_pair, random_phi
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, dtype, out):
+    import torch
+    import torch.distributed as dist
+    load_package()
+    from stereo_vision_amd import bands, diffstereo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        H, W, D, iters = 13, 45, 24, 3
+        left, right = random_pair(H, W, seed=8)
+        phi0 = random_phi(H, W, D, dtype, seed=2)
+        rb, re = bands.partition_rows(H, world)[rank]
+        g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype, row_begin=rb, row_end=re, device=0)
+        g.set_phi(phi0[rb:re])
+        runner = bands.BandRunner(bands.HipBandEngine(g, stage_through_host=True))
+        runner.exchange_all()
+        runner.iterate(iters)
+        energy = runner.energy()
+        whole = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+        whole.set_phi(phi0)
+        whole.iterate(iters)
+        same = np.array_equal(g.get_phi(), whole.get_phi()[rb:re])
+        e_ref = whole.energy()
+        e_ok = abs(energy - e_ref) <= 1e-9 * max(1.0, abs(e_ref))
+        if not (same and e_ok):
+            print("rank", rank, "phi same:", same, "energy", energy, "ref", e_ref, flush=True)
+        out[rank] = (bool(same), bool(e_ok))
+        g.close()
+        whole.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dtype", [(2, "f32"), (3, "f64")])
+def test_two_ranks_one_gpu(world, dtype):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), dtype, out), nprocs=world, join=True)
+    for rank in range(world):
+        assert out[rank] == (True, True), "rank %d: %s" % (rank, out[rank])
