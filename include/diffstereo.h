@@ -134,6 +134,14 @@ int ds_profile_end(ds_handle *h, int *n_launches, double *total_ms, double *min_
 /* Geometry of the handle (any pointer may be NULL). */
 int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_begin, int *row_end);
 
+/* How phi was placed in HBM at creation.  For large problems the library allocates phi in
+ * two plane groups and probes a few placements of the second group (timed sweeps), because
+ * the sweep runs ~15 % faster when its streams are spread over more than one of the three
+ * 96 GiB physical regions of MI355X's HBM; DS_PLACEMENT=off in the environment disables it.
+ * *tries = placements timed (0 = none), *probe_ms = red + black half-sweep time of the one
+ * kept, *split = 1 if the groups are separate allocations.  No counterpart in the reference. */
+int ds_placement_info(const ds_handle *h, int *tries, double *probe_ms, int *split);
+
 /* Order-independent 64-bit checksum of the band's phi (sum of the bit patterns of
  * all entries the reference would touch), to compare large states without copying. */
 int ds_checksum(ds_handle *h, uint64_t *out);

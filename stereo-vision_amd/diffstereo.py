@@ -40,6 +40,7 @@ SYMBOLS = {
     "ds_profile_begin": (_I, [_P, _I]),
     "ds_profile_end": (_I, [_P, _IP, _DP, _DP, _DP]),
     "ds_info": (_I, [_P, _IP, _IP, _IP, _IP, _IP, _IP]),
+    "ds_placement_info": (_I, [_P, _IP, _DP, _IP]),
     "ds_checksum": (_I, [_P, C.POINTER(C.c_uint64)]),
 }
 
@@ -172,6 +173,11 @@ class DiffusionGraph:
         n, tot, lo, hi = C.c_int(), C.c_double(), C.c_double(), C.c_double()
         self._chk(lib().ds_profile_end(self._h, C.byref(n), C.byref(tot), C.byref(lo), C.byref(hi)))
         return {"launches": n.value, "total_ms": tot.value, "min_ms": lo.value, "max_ms": hi.value}
+
+    def placement_info(self):
+        n, ms, sp = C.c_int(), C.c_double(), C.c_int()
+        self._chk(lib().ds_placement_info(self._h, C.byref(n), C.byref(ms), C.byref(sp)))
+        return {"tries": n.value, "probe_ms": ms.value, "split": bool(sp.value)}
 
     def checksum(self):
         v = C.c_uint64()
