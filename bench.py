@@ -143,8 +143,8 @@ def main():
         my_pl = valid_pairs(re - rb, W, D)
         kernel_s = prof["total_ms"] / 1e3
         achieved = bytes_per_pl * my_pl * args.steps / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        kernel = "ds::sweep_kernel<%s, %d>" % ("float" if dtype == "f32" else "double",
-                                               16 if D <= 64 else 32 if D <= 128 else 64)
+        kernel = "ds::sweep_kernel<%s, %d, false>" % ("float" if dtype == "f32" else "double",
+                                                      16 if D <= 64 else 32 if D <= 128 else 64)
         avg_launch_s = kernel_s / max(prof["launches"], 1)
         pmc_bytes = pmc_traffic(args.workload, kernel) if world == 1 else None
         line = {
@@ -167,7 +167,7 @@ def main():
                          "algorithmic_bytes_per_pixel_label": bytes_per_pl,
                          "launches": prof["launches"],
                          "avg_launch_ms": prof["total_ms"] / max(prof["launches"], 1),
-                         "rank": 0},
+                         "rank": 0, "placement": graph.placement_info()},
             "energy": energy,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -42,6 +42,7 @@ struct ds_handle {
     void *phi_b = nullptr;        // group B when allocated apart, else NULL
     double placement_ms = 0.0;    // probe result of the chosen placement (0 = not probed)
     int placement_tries = 0;
+    bool probing = false;         // launches belong to the placement probe
     size_t elem = 4;
 
     double *part_sum = nullptr, *part_max = nullptr;  // per-wavefront partials
@@ -152,8 +153,12 @@ int launch_sweep(ds_handle *h, int colour, int row_begin, int row_end)
     int rc = dispatch(h, [&](auto t, auto lpp) -> int {
         using T = decltype(t);
         constexpr int L = decltype(lpp)::value;
-        hipLaunchKernelGGL((ds::sweep_kernel<T, L>), grid, block, 0, h->stream, h->g, static_cast<T *>(h->phi),
-                           h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels);
+        if (h->probing)
+            hipLaunchKernelGGL((ds::sweep_kernel<T, L, true>), grid, block, 0, h->stream, h->g,
+                               static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels);
+        else
+            hipLaunchKernelGGL((ds::sweep_kernel<T, L, false>), grid, block, 0, h->stream, h->g,
+                               static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels);
         return DS_OK;
     });
     if (rc != DS_OK) return rc;
@@ -199,6 +204,11 @@ int init_phi(ds_handle *h)
 // Milliseconds of one red + one black half-sweep over the band with the current planes.
 int probe_sweeps(ds_handle *h, double *ms)
 {
+    struct Flag {
+        bool &f;
+        explicit Flag(bool &x) : f(x) { f = true; }
+        ~Flag() { f = false; }
+    } flag(h->probing);
     int rc = init_phi(h);
     const int r0 = h->g.row0, r1 = h->g.row0 + h->g.Hb;
     for (int colour = 0; colour < 2 && rc == DS_OK; ++colour) rc = launch_sweep(h, colour, r0, r1);

@@ -467,7 +467,9 @@ __device__ __forceinline__ void st4_nt(double *p, const V4<double> &x)
     __builtin_nontemporal_store(b, reinterpret_cast<d2 *>(p + 2));
 }
 
-template <typename T, int LPP>
+// PROBE only changes the kernel's name: launches made while ds_create times candidate
+// placements of phi show up apart from the real sweeps in a profile.
+template <typename T, int LPP, bool PROBE = false>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(Geometry g, T *__restrict__ phi,
                                                        const uint8_t *__restrict__ cost, T lambda,
                                                        int colour, int row_begin, int seg_pixels)
