@@ -254,6 +254,8 @@ int place_phi(ds_handle *h)
     }
     int max_tries = 8;
     if (const char *v = std::getenv("DS_PLACEMENT_TRIES")) max_tries = std::atoi(v) > 0 ? std::atoi(v) : 1;
+    const bool verbose = std::getenv("DS_PLACEMENT_VERBOSE") != nullptr;
+    const bool exhaustive = mode && std::strcmp(mode, "exhaustive") == 0;
     const size_t spacer_bytes = 16ull << 30;
     std::vector<void *> spacers;
     auto cleanup = [&]() {
@@ -297,6 +299,7 @@ int place_phi(ds_handle *h)
         }
         ++h->placement_tries;
         worst = ms > worst ? ms : worst;
+        if (verbose) std::fprintf(stderr, "[diffstereo] placement try %d (%zu spacers): %.3f ms\n", attempt, spacers.size(), ms);
         since_gain = (!h->phi_b || ms < 0.98 * best) ? 0 : since_gain + 1;
         if (!h->phi_b || ms < best) {
             (void)hipFree(h->phi_b);
@@ -305,6 +308,7 @@ int place_phi(ds_handle *h)
         } else {
             (void)hipFree(cand);
         }
+        if (exhaustive) continue;
         if (attempt > 0 && best <= 0.9 * worst) break;  // left the single-region state
         if (since_gain >= 3) break;                     // nothing better within 48 GiB
     }

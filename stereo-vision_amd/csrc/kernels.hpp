@@ -118,6 +118,11 @@ __device__ __forceinline__ double readlane(double x, int lane)
 }
 
 // min over the lanes strictly below this one inside its LPP-lane segment (+inf for the first).
+//
+// Each step is e = min(e, t) with t = e moved across lanes.  A lane without a source keeps
+// what t held before; t starts at +inf and afterwards only ever holds an earlier e of a
+// lower lane of the same segment, i.e. a min over labels that belong to this lane's prefix
+// anyway, so the stale value is harmless (min is idempotent) and t never needs to be reset.
 template <typename T, int LPP>
 __device__ __forceinline__ T excl_prefix_min(T v, int lseg)
 {
@@ -125,12 +130,13 @@ __device__ __forceinline__ T excl_prefix_min(T v, int lseg)
     const T inf = R::inf();
     T e = dpp<DPP_WAVE_SHR1>(inf, v);
     if (LPP < 64) e = (lseg == 0) ? inf : e;
-    e = R::min(e, dpp<DPP_ROW_SHR + 1>(inf, e));
-    e = R::min(e, dpp<DPP_ROW_SHR + 2>(inf, e));
-    e = R::min(e, dpp<DPP_ROW_SHR + 4>(inf, e));
-    e = R::min(e, dpp<DPP_ROW_SHR + 8>(inf, e));
-    if (LPP >= 32) e = R::min(e, dpp<DPP_ROW_BCAST15, 0xa>(inf, e));
-    if (LPP >= 64) e = R::min(e, dpp<DPP_ROW_BCAST31, 0xc>(inf, e));
+    T t = inf;
+    t = dpp<DPP_ROW_SHR + 1>(t, e); e = R::min(e, t);
+    t = dpp<DPP_ROW_SHR + 2>(t, e); e = R::min(e, t);
+    t = dpp<DPP_ROW_SHR + 4>(t, e); e = R::min(e, t);
+    t = dpp<DPP_ROW_SHR + 8>(t, e); e = R::min(e, t);
+    if (LPP >= 32) { t = dpp<DPP_ROW_BCAST15, 0xa>(t, e); e = R::min(e, t); }
+    if (LPP >= 64) { t = dpp<DPP_ROW_BCAST31, 0xc>(t, e); e = R::min(e, t); }
     return e;
 }
 
@@ -142,10 +148,11 @@ __device__ __forceinline__ T excl_suffix_min(T v, int lseg, int lane)
     const T inf = R::inf();
     T e = dpp<DPP_WAVE_SHL1>(inf, v);
     if (LPP < 64) e = (lseg == LPP - 1) ? inf : e;
-    e = R::min(e, dpp<DPP_ROW_SHL + 1>(inf, e));
-    e = R::min(e, dpp<DPP_ROW_SHL + 2>(inf, e));
-    e = R::min(e, dpp<DPP_ROW_SHL + 4>(inf, e));
-    e = R::min(e, dpp<DPP_ROW_SHL + 8>(inf, e));
+    T t = inf;
+    t = dpp<DPP_ROW_SHL + 1>(t, e); e = R::min(e, t);
+    t = dpp<DPP_ROW_SHL + 2>(t, e); e = R::min(e, t);
+    t = dpp<DPP_ROW_SHL + 4>(t, e); e = R::min(e, t);
+    t = dpp<DPP_ROW_SHL + 8>(t, e); e = R::min(e, t);
     // e(l) now covers the rest of the lane's 16-lane row; add the rows above it.
     if (LPP >= 32) {
         const int row = lane >> 4;
@@ -438,7 +445,7 @@ __device__ __forceinline__ void messages_any(const V4<T> psi[4], const T lam[4],
 // border, the first D columns, padded D) take the general path, which also skips the
 // vectors that hold nothing but +inf (labels d > j: 3 % of a 4K x 256 volume).
 //
-// Every byte is touched exactly once per launch, so loads and stores are non-temporal
+// Every byte is touched exactly once per launch, so f32 loads and stores are non-temporal
 // (measured 3 % faster than default-policy accesses at 4K x 256).
 __device__ __forceinline__ V4<float> ld4_nt(const float *p)
 {
@@ -446,26 +453,17 @@ __device__ __forceinline__ V4<float> ld4_nt(const float *p)
     const f4 x = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
     return {{x.x, x.y, x.z, x.w}};
 }
-__device__ __forceinline__ V4<double> ld4_nt(const double *p)
-{
-    using d2 = __attribute__((ext_vector_type(2))) double;
-    const d2 a = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p));
-    const d2 b = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p + 2));
-    return {{a.x, a.y, b.x, b.y}};
-}
+// f64: a lane's 32 bytes arrive as two 16-byte loads whose lanes are 32 bytes apart, so each
+// instruction uses half of every 128-byte line and relies on the cache to serve the other
+// half to the second instruction; non-temporal accesses give that up (measured 12 % slower).
+__device__ __forceinline__ V4<double> ld4_nt(const double *p) { return load4(p); }
 __device__ __forceinline__ void st4_nt(float *p, const V4<float> &x)
 {
     using f4 = __attribute__((ext_vector_type(4))) float;
     const f4 v = {x.v[0], x.v[1], x.v[2], x.v[3]};
     __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
 }
-__device__ __forceinline__ void st4_nt(double *p, const V4<double> &x)
-{
-    using d2 = __attribute__((ext_vector_type(2))) double;
-    const d2 a = {x.v[0], x.v[1]}, b = {x.v[2], x.v[3]};
-    __builtin_nontemporal_store(a, reinterpret_cast<d2 *>(p));
-    __builtin_nontemporal_store(b, reinterpret_cast<d2 *>(p + 2));
-}
+__device__ __forceinline__ void st4_nt(double *p, const V4<double> &x) { store4(p, x); }
 
 // PROBE only changes the kernel's name: launches made while ds_create times candidate
 // placements of phi show up apart from the real sweeps in a profile.

@@ -163,3 +163,31 @@ def test_error_paths():
     with pytest.raises(diffstereo.DiffStereoError):
         band.sweep(0, 0, 2)  # outside the band
     band.close()
+
+
+def test_placement_does_not_change_results(monkeypatch):
+    """A problem large enough for ds_create to place phi in two separately allocated plane
+    groups (and to probe placements) must give the same bits as one plain allocation."""
+    H, W, D = 258, 2048, 256
+    left, right, _ = synth.synthetic_pair(H, W, D)
+    monkeypatch.setenv("DS_PLACEMENT_TRIES", "3")
+    a = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    info = a.placement_info()
+    assert info["split"] and 1 <= info["tries"] <= 3 and info["probe_ms"] > 0
+    monkeypatch.setenv("DS_PLACEMENT", "off")
+    b = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    assert b.placement_info() == {"tries": 0, "probe_ms": 0.0, "split": False}
+    assert a.checksum() == b.checksum() == 0  # probing leaves phi in its initial state
+    a.iterate(3)
+    b.iterate(3)
+    assert a.checksum() == b.checksum()
+    assert np.array_equal(a.labels(0), b.labels(0))
+    ea, eb = a.energy(), b.energy()
+    assert ea == eb
+    assert np.array_equal(a.get_phi(100, 103), b.get_phi(100, 103))
+    f = FastOracle(left[:40], right[:40], D, 1.2, dtype="f32")  # top rows only: same neighbourhoods
+    f.iterate(3)
+    # rows 0..35 of the 40-row crop are unaffected by the crop's bottom edge after 3 iterations
+    assert np.array_equal(a.get_phi(0, 30), f.potentials[:30])
+    a.close()
+    b.close()
