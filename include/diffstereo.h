@@ -108,6 +108,18 @@ int ds_energy(ds_handle *h, double *energy, double *max_residual);
  * out: [rows][W]. */
 int ds_labels(ds_handle *h, int mode, uint32_t *out);
 
+/* Replaces CrossingOutGraph::initialize_with_epsilon + crossing_out + is_not_empty +
+ * simple_best_labeling (diffusion_stereo/src/crossing_out_graph.rs:67-183,187-246,307-327) on the
+ * current phi: vertices within epsilon of their pixel's minimum, edges within epsilon of their
+ * pixel pair's minimum, deletion to the greatest consistent sub-graph, then the smallest
+ * surviving label per pixel.  No O(D^2) edge mask is kept: edge tests are min-plus products,
+ * re-evaluated in whole-image passes until nothing changes (at most max_passes, else
+ * DS_ERR_STATE).  labels: [H][W], 0xffffffff where a pixel lost every label; alive_out
+ * (optional): [H][W][D] bytes, the reference's `vertices`; *not_empty = is_not_empty();
+ * *passes = relaxation passes run.  Whole-image handles only. */
+int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
+                    int *not_empty, int *passes);
+
 /* Replace direct access to the public field `potentials` (diffusion_graph.rs:43).
  * Rows [row_begin, row_end) may include the band's halo rows. */
 int ds_get_phi_rows(ds_handle *h, int row_begin, int row_end, void *out);

@@ -50,6 +50,10 @@ struct ds_handle {
     double *d_scalars = nullptr;                      // [0] energy, [1] max residual
     unsigned long long *d_checksum = nullptr;
     uint32_t *d_labels = nullptr;                     // [Hb][W]
+    uint8_t *co_alive = nullptr;                      // crossing-out vertex mask [2][Hb][Wh][Dpad]
+    void *co_gmin = nullptr;                          // [2][Hb][Wh][4] min edge penalty per (pixel, slot)
+    uint8_t *co_host_order = nullptr;                 // [Hb][W][D], only when the mask is asked for
+    int *co_flags = nullptr;                          // [0] changed, [1] some pixel empty
 
     hipStream_t own_stream = nullptr, stream = nullptr;
 
@@ -139,6 +143,10 @@ void release(ds_handle *h)
     (void)hipFree(h->d_scalars);
     (void)hipFree(h->d_checksum);
     (void)hipFree(h->d_labels);
+    (void)hipFree(h->co_alive);
+    (void)hipFree(h->co_gmin);
+    (void)hipFree(h->co_host_order);
+    (void)hipFree(h->co_flags);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -716,6 +724,90 @@ int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_beg
     if (dtype) *dtype = h->dtype;
     if (row_begin) *row_begin = h->g.row0;
     if (row_end) *row_end = h->g.row0 + h->g.Hb;
+    return DS_OK;
+}
+
+int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
+                    int *not_empty, int *passes)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!(epsilon >= 0.0) || max_passes < 1) return fail(h, DS_ERR_ARG, "epsilon must be >= 0 and max_passes >= 1");
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H)
+        return fail(h, DS_ERR_STATE, "ds_crossing_out needs the whole image (bands would need a mask halo exchange)");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    const size_t mask_bytes = (size_t)(2 * g.cost_colour_stride);
+    if (!h->co_alive) {
+        hipError_t e = hipMalloc(&h->co_alive, mask_bytes);
+        if (e == hipSuccess) e = hipMalloc(&h->co_gmin, (size_t)2 * g.Hb * g.Wh * 4 * h->elem);
+        if (e == hipSuccess) e = hipMalloc(&h->co_flags, 2 * sizeof(int));
+        if (e != hipSuccess)
+            return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP,
+                        std::string("hipMalloc(crossing-out state): ") + hipGetErrorString(e));
+    }
+    if (alive_out && !h->co_host_order) {
+        hipError_t e = hipMalloc(&h->co_host_order, (size_t)g.Hb * g.W * g.D);
+        if (e != hipSuccess)
+            return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP,
+                        std::string("hipMalloc(mask copy): ") + hipGetErrorString(e));
+    }
+    const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
+    HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
+    for (int colour = 0; colour < 2; ++colour) {
+        rc = dispatch(h, [&](auto t, auto lpp) -> int {
+            using T = decltype(t);
+            hipLaunchKernelGGL((ds::co_init_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
+                               static_cast<const T *>(h->phi), h->cost_px, (T)h->lambda, (T)epsilon, colour,
+                               h->seg_pixels, h->co_alive, static_cast<T *>(h->co_gmin));
+            return DS_OK;
+        });
+        if (rc != DS_OK) return rc;
+        HIPCHK(h, hipGetLastError());
+    }
+    int done = 0, host_flags[2] = {0, 0};
+    bool fixed = false;
+    while (done < max_passes && !fixed) {
+        HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
+        for (int colour = 0; colour < 2; ++colour) {
+            rc = dispatch(h, [&](auto t, auto lpp) -> int {
+                using T = decltype(t);
+                hipLaunchKernelGGL((ds::co_relax_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
+                                   static_cast<const T *>(h->phi), (T)h->lambda, (T)epsilon, colour, h->seg_pixels,
+                                   h->co_alive, static_cast<const T *>(h->co_gmin), h->co_flags);
+                return DS_OK;
+            });
+            if (rc != DS_OK) return rc;
+            HIPCHK(h, hipGetLastError());
+        }
+        HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        ++done;
+        fixed = host_flags[0] == 0;
+    }
+    if (!fixed) return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
+    HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
+    for (int colour = 0; colour < 2; ++colour) {
+        switch (h->lpp) {
+        case 16: hipLaunchKernelGGL(ds::co_labels_kernel<16>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels, h->co_flags + 1); break;
+        case 32: hipLaunchKernelGGL(ds::co_labels_kernel<32>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels, h->co_flags + 1); break;
+        default: hipLaunchKernelGGL(ds::co_labels_kernel<64>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels, h->co_flags + 1); break;
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (labels)
+        HIPCHK(h, hipMemcpyAsync(labels, h->d_labels, (size_t)g.Hb * g.W * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 h->stream));
+    if (alive_out) {
+        hipLaunchKernelGGL(ds::co_unpack_kernel, dim3(4096), block, 0, h->stream, g, h->co_alive, h->co_host_order);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(alive_out, h->co_host_order, (size_t)g.Hb * g.W * g.D, hipMemcpyDeviceToHost,
+                                 h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (not_empty) *not_empty = host_flags[1] == 0;
+    if (passes) *passes = done;
     return DS_OK;
 }
 

@@ -736,6 +736,220 @@ __global__ __launch_bounds__(kBlock) void labels_kernel(Geometry g, const T *__r
     }
 }
 
+// ---- epsilon-consistency ("crossing out") --------------------------------------------
+// Reference: diffusion_stereo/src/crossing_out_graph.rs:67-183.  A vertex (t, d) starts
+// alive iff d <= j and f_t(d) <= min_d f_t + eps (:78-93); an edge (t, n, d, d') is usable
+// iff it exists and g_tt'(d, d') <= min_{d,d'} g_tt' + eps (:102-130).  crossing_out
+// (:135-183) deletes vertices until every alive (t, d) has, towards every existing
+// neighbour, a usable edge to an alive (t', d').  That greatest fixed point does not depend
+// on the order of deletions, so it is reached here by repeated whole-image passes that
+// update one byte mask in place (deletions are monotone: a stale read only delays one).
+//
+// The reference keeps an O(D^2) edge mask per pixel and slot; here "is there a usable
+// edge to an alive label of t'" is one more min-plus product: with psi restricted to the
+// neighbour's alive labels (+inf elsewhere),
+//     exists d': usable  <=>  phi[t][n][d] + min_{d' alive} (lambda|d-d'| + psi(d')) <= gmin + eps
+// evaluated with the same scans as the sweep.  Masks use the packed cost's layout
+// alive[colour][row][jc][dp] (one byte per label, a dword per lane).
+template <typename T> __device__ __forceinline__ V4<T> load_own(const Geometry &g, const T *phi, int colour,
+                                                                const Pixel &p, int n)
+{
+    return (p.active && p.has[n]) ? load4(phi + g.plane_off[colour][n] + p.own) : splat(T(0));
+}
+
+__device__ __forceinline__ long long mask_off(const Geometry &g, const Pixel &p, int n)
+{
+    // byte offset, inside one colour's mask, of the lane's 4 labels at the neighbour in slot n
+    // (n < 0: the pixel itself); rows are band rows (no halo)
+    const long long row = (long long)g.Wh * g.Dpad;
+    switch (n) {
+    case 0: return p.cost + (long long)(((p.j & 1) ? 1 : 0) - 1) * g.Dpad;  // (i, j-1): slot jc + s - 1
+    case 1: return p.cost - row;
+    case 2: return p.cost + (long long)((p.j & 1) ? 1 : 0) * g.Dpad;        // (i, j+1): slot jc + s
+    case 3: return p.cost + row;
+    default: return p.cost;
+    }
+}
+
+// First pass: vertex mask and gmin[t][n]; mode bit: see co_relax_kernel.
+template <typename T, int LPP>
+__global__ __launch_bounds__(kBlock) void co_init_kernel(Geometry g, const T *__restrict__ phi,
+                                                         const uint8_t *__restrict__ cost, T lambda, T eps,
+                                                         int colour, int seg_pixels,
+                                                         uint8_t *__restrict__ alive, T *__restrict__ gmin)
+{
+    using R = Real<T>;
+    constexpr int PPW = 64 / LPP;
+    const T inf = R::inf();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int i = g.row0 + blockIdx.y;
+    const int s = (i + colour) & 1;
+    T lam[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
+    const uint8_t *cost_c = cost + colour * g.cost_colour_stride;
+    uint8_t *alive_c = alive + colour * g.cost_colour_stride;
+    T *gmin_c = gmin + (long long)colour * g.Hb * g.Wh * 4;
+
+    const int seg0 = blockIdx.x * seg_pixels;
+    const int groups = seg_pixels / PPW;
+    for (int grp = wave; grp < groups; grp += kBlock / 64) {
+        const int jc = seg0 + grp * PPW + q;
+        const Pixel p = locate(g, i, s, jc, d0);
+        V4<T> psi[4], M[4], own[4];
+        load_psi(g, phi, 1 - colour, p, psi);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) own[n] = load_own(g, phi, colour, p, n);
+        const V4<T> qc = load_cost<T>(cost_c, p);
+        messages<T, LPP>(psi, lam, lambda, lseg, lane, M);
+        const int K = p.j < g.D - 1 ? p.j : g.D - 1;
+        T f[4], fmin = inf, gm[4] = {inf, inf, inf, inf};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool valid = p.active && (d0 + k <= K);
+            T sp = T(0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) sp += p.has[n] ? own[n].v[k] : T(0);
+            f[k] = qc.v[k] - sp;
+            if (valid) {
+                fmin = R::min(fmin, f[k]);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) gm[n] = R::min(gm[n], own[n].v[k] + M[n].v[k]);
+            }
+        }
+        fmin = segment_min<T, LPP>(fmin);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) gm[n] = segment_min<T, LPP>(gm[n]);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool valid = p.active && (d0 + k <= K);
+            if (valid && f[k] <= fmin + eps) bits |= 1u << (8 * k);
+        }
+        if (p.active) *reinterpret_cast<uint32_t *>(alive_c + p.cost) = bits;
+        if (p.j < g.W && lseg == 0) {
+            T *dst = gmin_c + ((long long)(i - g.row0) * g.Wh + jc) * 4;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) dst[n] = gm[n];
+        }
+    }
+}
+
+// One relaxation pass over one colour; *changed is set if any vertex died.
+template <typename T, int LPP>
+__global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *__restrict__ phi, T lambda,
+                                                          T eps, int colour, int seg_pixels,
+                                                          uint8_t *alive, const T *__restrict__ gmin,
+                                                          int *__restrict__ changed)
+{
+    using R = Real<T>;
+    constexpr int PPW = 64 / LPP;
+    const T inf = R::inf();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int i = g.row0 + blockIdx.y;
+    const int s = (i + colour) & 1;
+    T lam[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
+    uint8_t *alive_c = alive + colour * g.cost_colour_stride;
+    const uint8_t *alive_o = alive + (1 - colour) * g.cost_colour_stride;
+    const T *gmin_c = gmin + (long long)colour * g.Hb * g.Wh * 4;
+
+    const int seg0 = blockIdx.x * seg_pixels;
+    const int groups = seg_pixels / PPW;
+    bool any = false;
+    for (int grp = wave; grp < groups; grp += kBlock / 64) {
+        const int jc = seg0 + grp * PPW + q;
+        const Pixel p = locate(g, i, s, jc, d0);
+        V4<T> psi[4], M[4], own[4];
+        load_psi(g, phi, 1 - colour, p, psi);
+        uint32_t mine = p.active ? *reinterpret_cast<const volatile uint32_t *>(alive_c + p.cost) : 0u;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            own[n] = load_own(g, phi, colour, p, n);
+            uint32_t nb = 0;
+            if (p.active && p.has[n]) nb = *reinterpret_cast<const volatile uint32_t *>(alive_o + mask_off(g, p, n));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!((nb >> (8 * k)) & 1u)) psi[n].v[k] = inf;  // dead labels of t' offer no edge
+        }
+        messages<T, LPP>(psi, lam, lambda, lseg, lane, M);
+        T gm[4] = {T(0), T(0), T(0), T(0)};
+        if (p.j < g.W) {
+            const T *src = gmin_c + ((long long)(i - g.row0) * g.Wh + jc) * 4;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) gm[n] = src[n];
+        }
+        uint32_t next = mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((mine >> (8 * k)) & 1u)) continue;
+            bool ok = true;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (p.has[n]) ok = ok && (own[n].v[k] + M[n].v[k] <= gm[n] + eps);
+            if (!ok) next &= ~(1u << (8 * k));
+        }
+        if (p.active && next != mine) {
+            *reinterpret_cast<volatile uint32_t *>(alive_c + p.cost) = next;
+            any = true;
+        }
+    }
+    if (__any(any) && lane == 0) atomicOr(changed, 1);
+}
+
+// Smallest alive label per pixel (crossing_out_graph.rs:307-327); 0xffffffff and
+// *empty = 1 where a pixel has none (vertices_exist false, :196-211).
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void co_labels_kernel(Geometry g, const uint8_t *__restrict__ alive, int colour,
+                                                           int seg_pixels, uint32_t *__restrict__ out,
+                                                           int *__restrict__ empty)
+{
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int i = g.row0 + blockIdx.y;
+    const int s = (i + colour) & 1;
+    const uint8_t *alive_c = alive + colour * g.cost_colour_stride;
+    const int seg0 = blockIdx.x * seg_pixels;
+    const int groups = seg_pixels / PPW;
+    for (int grp = wave; grp < groups; grp += kBlock / 64) {
+        const int jc = seg0 + grp * PPW + q;
+        const Pixel p = locate(g, i, s, jc, d0);
+        const uint32_t bits = p.active ? *reinterpret_cast<const uint32_t *>(alive_c + p.cost) : 0u;
+        int first = 0x7fffffff;
+#pragma unroll
+        for (int k = 3; k >= 0; --k)
+            if ((bits >> (8 * k)) & 1u) first = d0 + k;
+#pragma unroll
+        for (int m = LPP / 2; m >= 1; m >>= 1) {
+            const int o = __shfl_xor(first, m);
+            first = o < first ? o : first;
+        }
+        if (p.j < g.W && lseg == 0) {
+            out[(long long)(i - g.row0) * g.W + p.j] = first == 0x7fffffff ? 0xffffffffu : (uint32_t)first;
+            if (first == 0x7fffffff) atomicOr(empty, 1);
+        }
+    }
+}
+
+// alive[colour][row][jc][dp] -> host-order bytes out[row][j][d] (reference: vertices[i][j][d]).
+__global__ __launch_bounds__(kBlock) void co_unpack_kernel(Geometry g, const uint8_t *__restrict__ alive,
+                                                           uint8_t *__restrict__ out)
+{
+    const long long total = (long long)g.Hb * g.W * g.D;
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * kBlock) {
+        const int d = (int)(idx % g.D);
+        const long long px = idx / g.D;
+        const int j = (int)(px % g.W), r = (int)(px / g.W);
+        const int colour = (g.row0 + r + j) & 1;
+        out[idx] = alive[colour * g.cost_colour_stride + ((long long)r * g.Wh + (j >> 1)) * g.Dpad + d] & 1u;
+    }
+}
+
 // ---- stage 1: cost volume --------------------------------------------------------------
 // cost[d][r][j] = |L[i][j] - R[i][j-d]| for d <= j, else 0; r = band row, i = row0 + r.
 // One thread per 4 consecutive bytes of the label-major volume: lanes run along j, so

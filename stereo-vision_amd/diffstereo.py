@@ -32,6 +32,7 @@ SYMBOLS = {
     "ds_sweep": (_I, [_P, _I, _I, _I]),
     "ds_energy": (_I, [_P, _DP, _DP]),
     "ds_labels": (_I, [_P, _I, _P]),
+    "ds_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
     "ds_get_phi_rows": (_I, [_P, _I, _I, _P]),
     "ds_set_phi_rows": (_I, [_P, _I, _I, _P]),
     "ds_get_phi": (_I, [_P, _P]),
@@ -143,6 +144,19 @@ class DiffusionGraph:
     def labels(self, mode=0):
         out = np.empty((self.rows, self.W), dtype=np.uint32)
         self._chk(lib().ds_labels(self._h, int(mode), _ptr(out)))
+        return out
+
+    def crossing_out(self, epsilon, max_passes=100000, with_mask=False):
+        """initialize_with_epsilon + crossing_out + simple_best_labeling on the GPU
+        (crossing_out_graph.rs:67-183,307-327).  Returns dict(labels, not_empty, passes[, alive])."""
+        labels = np.empty((self.rows, self.W), dtype=np.uint32)
+        alive = np.empty((self.rows, self.W, self.D), dtype=np.uint8) if with_mask else None
+        ne, n = C.c_int(), C.c_int()
+        self._chk(lib().ds_crossing_out(self._h, float(epsilon), int(max_passes), _ptr(labels),
+                                        _ptr(alive) if with_mask else None, C.byref(ne), C.byref(n)))
+        out = {"labels": labels, "not_empty": bool(ne.value), "passes": n.value}
+        if with_mask:
+            out["alive"] = alive
         return out
 
     def get_phi(self, row_begin=None, row_end=None):

@@ -6,19 +6,26 @@
 
 namespace stereo {
 
-CrossingOutGraph CrossingOutGraph::initialize(DiffusionGraph g)
+CrossingOutGraph CrossingOutGraph::initialize(DiffusionGraph g, bool on_device)
 {
     CrossingOutGraph c(std::move(g));
+    c.on_device_ = on_device;
     c.H_ = c.diffusion_graph.height();
     c.W_ = c.diffusion_graph.width();
     c.D_ = c.diffusion_graph.max_disparity;
     c.vertices_.assign(c.H_ * c.W_ * c.D_, 1);
-    c.edges_.assign(c.H_ * c.W_ * c.D_ * 4 * c.D_, 1);
+    if (!on_device) c.edges_.assign(c.H_ * c.W_ * c.D_ * 4 * c.D_, 1);
     return c;
+}
+
+void CrossingOutGraph::need_host_masks(const char *what) const
+{
+    if (on_device_) throw std::logic_error(std::string(what) + " needs the host edge mask (initialize(..., false))");
 }
 
 void CrossingOutGraph::initialize_with_epsilon(double epsilon)
 {
+    need_host_masks("initialize_with_epsilon");
     initialize_vertices(epsilon);
     initialize_edges(epsilon);
 }
@@ -54,6 +61,7 @@ void CrossingOutGraph::initialize_edges(double epsilon)
 
 void CrossingOutGraph::crossing_out()
 {
+    need_host_masks("crossing_out");
     const DiffusionGraph &g = diffusion_graph;
     bool change_indicator = true;
     while (change_indicator) {
@@ -90,7 +98,12 @@ void CrossingOutGraph::crossing_out()
     }
 }
 
-bool CrossingOutGraph::is_not_empty() const { return vertices_exist() && edges_exist(); }
+bool CrossingOutGraph::is_not_empty() const
+{
+    // after the device closure every alive vertex has an alive edge in every direction,
+    // so edges_exist() is implied by vertices_exist()
+    return vertices_exist() && (on_device_ || edges_exist());
+}
 
 bool CrossingOutGraph::vertices_exist() const
 {
@@ -106,6 +119,7 @@ bool CrossingOutGraph::vertices_exist() const
 
 bool CrossingOutGraph::edges_exist() const
 {
+    need_host_masks("edges_exist");
     const DiffusionGraph &g = diffusion_graph;
     for (std::size_t i = 0; i < H_; ++i)
         for (std::size_t j = 0; j < W_; ++j)
@@ -132,6 +146,18 @@ std::size_t CrossingOutGraph::diffusion_while_not_consistent(double epsilon, std
         if (verbose) {
             std::printf("%zu iterations of diffusion ended\n", i + batch_size - 1);
             std::printf("Initializing crossing out graph with epsilon ...\n");
+        }
+        if (on_device_) {
+            int passes = 0;
+            const bool ok = diffusion_graph.crossing_out_on_device(epsilon, vertices_, &passes);
+            if (verbose) std::printf("Crossing out is done (%d passes on the device)\n", passes);
+            if (ok) {
+                if (verbose) std::printf("Graph is consistent. Diffusion is done\n");
+                return i + batch_size - 1;
+            }
+            if (verbose) std::printf("Need more diffusion iterations\n");
+            i += batch_size;
+            continue;
         }
         initialize_with_epsilon(epsilon);
         if (is_not_empty()) {
@@ -194,6 +220,7 @@ void CrossingOutGraph::cross_vertex(std::size_t i, std::size_t j, std::size_t di
 
 Matrix CrossingOutGraph::find_best_labeling()
 {
+    need_host_masks("find_best_labeling");
     Matrix m(H_, std::vector<std::size_t>(W_, 0));
     for (std::size_t i = 0; i < H_; ++i)
         for (std::size_t j = 0; j < W_; ++j) {

@@ -1,7 +1,11 @@
 // Host-side CrossingOutGraph: epsilon-consistent sub-graph and labeling
 // (diffusion_stereo/src/crossing_out_graph.rs:33-365).  The diffusion batches run on
-// the GPU through DiffusionGraph; the masks live on the host, as in the reference,
-// and need O(H*W*4*D^2) bytes, so this labeling is for small images only.
+// the GPU through DiffusionGraph.  Two modes:
+//   host masks   - vertex and edge masks on the host, as in the reference; the edge mask
+//                  needs O(H*W*4*D^2) bytes, so this is for small images and for
+//                  find_best_labeling;
+//   device       - initialize_with_epsilon + crossing_out run on the GPU (ds_crossing_out),
+//                  only the resulting vertex mask comes back; any image size.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -14,7 +18,9 @@ namespace stereo {
 class CrossingOutGraph {
 public:
     // crossing_out_graph.rs:51-59; both masks start all-true (main.rs:49-50).
-    static CrossingOutGraph initialize(DiffusionGraph diffusion_graph);
+    // on_device: see above; the edge mask is then never allocated.
+    static CrossingOutGraph initialize(DiffusionGraph diffusion_graph, bool on_device = false);
+    bool on_device() const { return on_device_; }
 
     DiffusionGraph diffusion_graph;
 
@@ -54,7 +60,9 @@ private:
     {
         return (((i * W_ + j) * D_ + d) * 4 + n) * D_ + n_d;
     }
+    void need_host_masks(const char *what) const;
     std::size_t H_ = 0, W_ = 0, D_ = 0;
+    bool on_device_ = false;
     std::vector<std::uint8_t> vertices_, edges_;
 };
 

@@ -262,6 +262,16 @@ Matrix DiffusionGraph::belief_depth_map()
     return labels_to_matrix(lab, H_, W_);
 }
 
+bool DiffusionGraph::crossing_out_on_device(double epsilon, std::vector<std::uint8_t> &vertices, int *passes)
+{
+    push();
+    vertices.assign(H_ * W_ * max_disparity, 0);
+    int not_empty = 0, n = 0;
+    check(ds_crossing_out(h_, epsilon, 1 << 30, nullptr, vertices.data(), &not_empty, &n));
+    if (passes) *passes = n;
+    return not_empty != 0;
+}
+
 void DiffusionGraph::build_depth_map(std::size_t iteration)
 {
     pgm_writer(depth_map(), "./images/results/result_" + std::to_string(iteration) + ".pgm", max_disparity);

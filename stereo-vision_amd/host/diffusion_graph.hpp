@@ -60,6 +60,10 @@ public:
     Matrix depth_map();          // :376-390 without the file write: argmin_d f_t(d)
     Matrix belief_depth_map();   // argmin_d of f_t after the pixel's vertex step (:302-317)
     void build_depth_map(std::size_t iteration);                            // :376-390
+    // CrossingOutGraph::initialize_with_epsilon + crossing_out on the current phi
+    // (crossing_out_graph.rs:67-183) on the device; vertices[i][j][d] is the resulting
+    // vertex mask.  Returns is_not_empty() (:187-193).
+    bool crossing_out_on_device(double epsilon, std::vector<std::uint8_t> &vertices, int *passes = nullptr);
 
 private:
     DiffusionGraph() = default;

@@ -130,6 +130,33 @@ int main()
         c.set_vertex(0, 0, 0, false);
         CHECK(!c.is_not_empty());
     }
+    {   // device crossing-out against the host masks on the same phi, and the whole
+        // diffusion_while_not_consistent loop (crossing_out_graph.rs:254-275) in both modes
+        const Img left{{3, 9, 4, 4, 7, 1}, {2, 8, 5, 3, 7, 2}, {3, 9, 5, 4, 6, 1}, {1, 2, 3, 4, 5, 6}};
+        const Img right{{9, 4, 4, 7, 1, 0}, {8, 5, 3, 7, 2, 0}, {9, 5, 4, 6, 1, 0}, {2, 3, 4, 5, 6, 0}};
+        for (double eps : {0.01, 2.0, 25.0}) {
+            CrossingOutGraph host = CrossingOutGraph::initialize(DiffusionGraph::initialize(left, right, 4, 1.2));
+            host.diffusion_graph.diffusion(1, 7, false);
+            host.initialize_with_epsilon(eps);
+            host.crossing_out();
+            std::vector<std::uint8_t> dev;
+            const bool ok = host.diffusion_graph.crossing_out_on_device(eps, dev);
+            CHECK(ok == host.is_not_empty());
+            bool same = true;
+            for (std::size_t i = 0; i < 4; ++i)
+                for (std::size_t j = 0; j < 6; ++j)
+                    for (std::size_t d = 0; d < 4; ++d) same = same && (dev[(i * 6 + j) * 4 + d] != 0) == host.vertex(i, j, d);
+            CHECK(same);
+        }
+        CrossingOutGraph a = CrossingOutGraph::initialize(DiffusionGraph::initialize(left, right, 4, 1.2), false);
+        CrossingOutGraph b = CrossingOutGraph::initialize(DiffusionGraph::initialize(left, right, 4, 1.2), true);
+        const double eps = 1. / 240.;
+        const std::size_t na = a.diffusion_while_not_consistent(eps, 50, 100, false);
+        const std::size_t nb = b.diffusion_while_not_consistent(eps, 50, 100, false);
+        CHECK(na == nb);
+        CHECK(a.simple_best_labeling() == b.simple_best_labeling());
+        CHECK(b.is_not_empty());
+    }
     {   // diffusion_stereo/src/utils.rs:214-247
         CHECK(number_of_neighbors(0, 1, 2, 3) == 3 && number_of_neighbors(1, 1, 3, 3) == 4);
         CHECK(check_disparity_map(Matrix{{0, 0}, {0, 1}}) && !check_disparity_map(Matrix{{0, 2, 1}}));

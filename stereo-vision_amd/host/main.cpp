@@ -4,12 +4,13 @@
 //
 //   stereovision LEFT.pgm RIGHT.pgm OUT.pgm [--max-disparity N] [--smoothing X]
 //                [--epsilon E] [--batch B] [--max-batches M] [--dtype f64|f32]
-//                [--decode crossing|belief] [--iterations K] [--quiet]
+//                [--decode crossing|crossing-host|belief] [--iterations K] [--quiet]
 //
 // --decode crossing (default) is the reference pipeline: diffusion batches on the GPU
-// until the epsilon-consistent sub-graph is non-empty, then the smallest surviving
-// label per pixel (host masks: small images only).  --decode belief runs --iterations
-// diffusion iterations and takes the per-pixel argmin on the GPU (any size).
+// until the epsilon-consistent sub-graph is non-empty (crossing out on the GPU too), then
+// the smallest surviving label per pixel.  --decode crossing-host keeps the reference's
+// vertex and edge masks on the host instead (O(H*W*D^2) bytes: small images only).
+// --decode belief runs --iterations diffusion iterations and takes the per-pixel argmin.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,7 +32,7 @@ int main(int argc, char **argv)
     std::size_t max_disparity = 40, batch = 200, max_batches = 1000, iterations = 200;
     double smoothing = 1.2, epsilon = -1.;
     int dtype = DS_F64;
-    bool crossing = true, verbose = true;
+    bool crossing = true, host_masks = false, verbose = true;
     for (int a = 4; a < argc; ++a) {
         const std::string o = argv[a];
         auto need = [&](const char *name) -> const char * {
@@ -48,7 +49,15 @@ int main(int argc, char **argv)
         else if (o == "--max-batches") max_batches = std::strtoul(need("--max-batches"), nullptr, 10);
         else if (o == "--iterations") iterations = std::strtoul(need("--iterations"), nullptr, 10);
         else if (o == "--dtype") dtype = std::strcmp(need("--dtype"), "f32") == 0 ? DS_F32 : DS_F64;
-        else if (o == "--decode") crossing = std::strcmp(need("--decode"), "belief") != 0;
+        else if (o == "--decode") {
+            const std::string mode = need("--decode");
+            if (mode != "crossing" && mode != "crossing-host" && mode != "belief") {
+                std::fprintf(stderr, "unknown --decode %s\n", mode.c_str());
+                return 2;
+            }
+            crossing = mode != "belief";
+            host_masks = mode == "crossing-host";
+        }
         else if (o == "--quiet") verbose = false;
         else {
             std::fprintf(stderr, "unknown option %s\n", o.c_str());
@@ -65,7 +74,7 @@ int main(int argc, char **argv)
         DiffusionGraph graph = DiffusionGraph::initialize(left.matrix, right.matrix, max_disparity, smoothing, dtype);
         Matrix disparity_map;
         if (crossing) {
-            CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph));
+            CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph), !host_masks);
             cog.diffusion_while_not_consistent(epsilon, batch, max_batches, verbose);
             std::printf("Finding disparity map ...\n");
             disparity_map = cog.simple_best_labeling();

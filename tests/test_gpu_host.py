@@ -20,15 +20,18 @@ def test_host_known_answers():
     assert "host KATs ok" in out.stdout
 
 
+@pytest.mark.parametrize("decode", ["crossing", "crossing-host"])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_cli_reference_pipeline_on_bundled_pair(tmp_path, golden_dir, dtype):
+def test_cli_reference_pipeline_on_bundled_pair(tmp_path, golden_dir, dtype, decode):
     """main's pipeline with its own constants (D = 40, lambda = 1.2, eps = 1/(10WH), batch
-    200): GPU checkerboard diffusion + host crossing-out must give the disparity map the
-    sequential CPU restatement of the reference gives (25/25 pixels)."""
+    200): GPU checkerboard diffusion + crossing-out (on the GPU, or with the reference's
+    host masks) must give the disparity map the sequential CPU restatement of the
+    reference gives (25/25 pixels)."""
     gold = np.load(os.path.join(golden_dir, "bundled_main.npz"))
     out_pgm = tmp_path / "best_labeling.pgm"
     run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
-                          os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--dtype", dtype, "--quiet"],
+                          os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--dtype", dtype, "--decode", decode,
+                          "--quiet"],
                          capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert run.returncode == 0, run.stdout + run.stderr
     assert "Disparity map is consistent: true" in run.stdout
