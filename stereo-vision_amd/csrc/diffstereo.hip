@@ -780,10 +780,17 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
             if (rc != DS_OK) return rc;
             HIPCHK(h, hipGetLastError());
         }
-        HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         ++done;
         fixed = host_flags[0] == 0;
+        if (host_flags[1] && g.H * g.W > 1) {
+            // A pixel without alive vertices takes all support from its neighbours, they from
+            // theirs, and the pixel grid is connected: the greatest consistent sub-graph is
+            // empty.  Skip the passes that would spread that over the image.
+            HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
+            fixed = true;
+        }
     }
     if (!fixed) return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
     HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));

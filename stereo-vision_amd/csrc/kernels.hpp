@@ -836,7 +836,8 @@ __global__ __launch_bounds__(kBlock) void co_init_kernel(Geometry g, const T *__
     }
 }
 
-// One relaxation pass over one colour; *changed is set if any vertex died.
+// One relaxation pass over one colour; changed[0] is set if any vertex died, changed[1] if
+// some pixel has no alive vertex left.
 template <typename T, int LPP>
 __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *__restrict__ phi, T lambda,
                                                           T eps, int colour, int seg_pixels,
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
 
     const int seg0 = blockIdx.x * seg_pixels;
     const int groups = seg_pixels / PPW;
-    bool any = false;
+    bool any = false, lost = false;
     for (int grp = wave; grp < groups; grp += kBlock / 64) {
         const int jc = seg0 + grp * PPW + q;
         const Pixel p = locate(g, i, s, jc, d0);
@@ -896,8 +897,13 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
             *reinterpret_cast<volatile uint32_t *>(alive_c + p.cost) = next;
             any = true;
         }
+        uint32_t left_alive = p.active ? next : 0u;
+#pragma unroll
+        for (int m = LPP / 2; m >= 1; m >>= 1) left_alive |= __shfl_xor(left_alive, m);
+        if (p.j < g.W && lseg == 0 && left_alive == 0u) lost = true;
     }
     if (__any(any) && lane == 0) atomicOr(changed, 1);
+    if (__any(lost) && lane == 0) atomicOr(changed + 1, 1);
 }
 
 // Smallest alive label per pixel (crossing_out_graph.rs:307-327); 0xffffffff and
