@@ -22,6 +22,8 @@ thread_local std::string g_create_error;
 
 }  // namespace
 
+constexpr int kReduceBlocks = 1024;  // first-stage blocks of the energy reduction
+
 struct ds_handle {
     ds::Geometry g{};
     int dtype = DS_F32;
@@ -374,9 +376,13 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     {
         const int ppw = 64 / h->lpp;
         const int per_round = (ds::kBlock / 64) * ppw;  // pixels one pass of the block's 4 waves covers
-        // 4 passes per block: short segments measured best at 4K x 256 (5.55 vs 5.70 ms at 16)
+        // Passes of the block's 4 wavefronts over its segment.  Measured at 4K (ms per launch,
+        // 1 / 2 / 4 passes): D=256 f32 5.38 / 5.44 / 5.48, f64 11.13 / 11.39 / 11.52;
+        // D=128 f32 2.98 / 2.72 / 2.76, f64 5.67 / - / 5.80; D=40 f32 0.99 / 0.91 / 0.92.
         int rounds = (g.Wh + per_round - 1) / per_round;
-        if (rounds > 4) rounds = 4;
+        int cap = (h->lpp == 64 || (h->lpp == 32 && dtype == DS_F64)) ? 1 : 2;
+        if (const char *e = std::getenv("DS_ROUNDS")) cap = std::atoi(e) > 0 ? std::atoi(e) : cap;  // tuning knob
+        if (rounds > cap) rounds = cap;
         if (rounds < 1) rounds = 1;
         h->seg_pixels = rounds * per_round;
         h->grid_x = (g.Wh + h->seg_pixels - 1) / h->seg_pixels;
@@ -403,8 +409,9 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     CREATE_HIPCHK(hipMalloc(&h->cost_px, (size_t)(2 * g.cost_colour_stride)));
     // phi is allocated last, by place_phi(), once the kernels it probes with can run
     h->part_n = 2ll * h->grid_x * g.Hb * (ds::kBlock / 64);
-    CREATE_HIPCHK(hipMalloc(&h->part_sum, (size_t)h->part_n * sizeof(double)));
-    CREATE_HIPCHK(hipMalloc(&h->part_max, (size_t)h->part_n * sizeof(double)));
+    // + kReduceBlocks entries behind the partials for the first reduction stage's results
+    CREATE_HIPCHK(hipMalloc(&h->part_sum, (size_t)(h->part_n + kReduceBlocks) * sizeof(double)));
+    CREATE_HIPCHK(hipMalloc(&h->part_max, (size_t)(h->part_n + kReduceBlocks) * sizeof(double)));
     CREATE_HIPCHK(hipMalloc(&h->d_scalars, 2 * sizeof(double)));
     CREATE_HIPCHK(hipMalloc(&h->d_checksum, sizeof(unsigned long long)));
     CREATE_HIPCHK(hipMalloc(&h->d_labels, (size_t)g.Hb * W * sizeof(uint32_t)));
@@ -588,7 +595,6 @@ int ds_energy(ds_handle *h, double *energy, double *max_residual)
     if (rc != DS_OK) return rc;
     const dim3 grid(h->grid_x, h->g.Hb), block(ds::kBlock);
     const long long half = h->part_n / 2;
-    HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 2 * sizeof(double), h->stream));
     for (int colour = 0; colour < 2; ++colour) {
         rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
@@ -600,8 +606,13 @@ int ds_energy(ds_handle *h, double *energy, double *max_residual)
         if (rc != DS_OK) return rc;
         HIPCHK(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(ds::reduce_partials_kernel, dim3(1), block, 0, h->stream, h->part_sum, h->part_max,
-                       h->part_n, h->d_scalars, h->d_scalars + 1);
+    const long long chunk = (h->part_n + kReduceBlocks - 1) / kReduceBlocks;
+    hipLaunchKernelGGL(ds::reduce_partials_kernel, dim3(kReduceBlocks), block, 0, h->stream, h->part_sum,
+                       h->part_max, h->part_n, chunk, h->part_sum + h->part_n, h->part_max + h->part_n);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(ds::reduce_partials_kernel, dim3(1), block, 0, h->stream, h->part_sum + h->part_n,
+                       h->part_max + h->part_n, (long long)kReduceBlocks, (long long)kReduceBlocks,
+                       h->d_scalars, h->d_scalars + 1);
     HIPCHK(h, hipGetLastError());
     double host[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(host, h->d_scalars, sizeof host, hipMemcpyDeviceToHost, h->stream));

@@ -634,15 +634,20 @@ __global__ __launch_bounds__(kBlock) void energy_kernel(Geometry g, const T *__r
     }
 }
 
-// Deterministic second stage: one block sums / maxes n partials.
+// Deterministic later stages: block b sums / maxes partials [b * chunk, (b + 1) * chunk) in a
+// fixed order into out[b].  Run once with many blocks, then once with one block over the
+// block results.
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double *__restrict__ part_sum,
                                                                  const double *__restrict__ part_max,
-                                                                 long long n, double *__restrict__ sum_io,
-                                                                 double *__restrict__ max_io)
+                                                                 long long n, long long chunk,
+                                                                 double *__restrict__ out_sum,
+                                                                 double *__restrict__ out_max)
 {
     __shared__ double ssum[kBlock], smax[kBlock];
+    const long long begin = (long long)blockIdx.x * chunk;
+    const long long end = begin + chunk < n ? begin + chunk : n;
     double a = 0.0, b = 0.0;
-    for (long long k = threadIdx.x; k < n; k += kBlock) {
+    for (long long k = begin + threadIdx.x; k < end; k += kBlock) {
         a += part_sum[k];
         b = b > part_max[k] ? b : part_max[k];
     }
@@ -658,8 +663,8 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double *_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        *sum_io += ssum[0];
-        *max_io = *max_io > smax[0] ? *max_io : smax[0];
+        out_sum[blockIdx.x] = ssum[0];
+        out_max[blockIdx.x] = smax[0];
     }
 }
 
@@ -1027,21 +1032,25 @@ __global__ __launch_bounds__(kBlock) void pack_cost_kernel(Geometry g, const uin
 template <typename T>
 __global__ __launch_bounds__(kBlock) void init_phi_kernel(Geometry g, T *__restrict__ phi)
 {
-    const long long per_plane = (long long)(g.Hb + 2) * g.Wh * g.Dpad;
+    // one thread per 4 consecutive labels (Dpad is a multiple of 4): one 16 / 32 B store
+    const int quads = g.Dpad / 4;
+    const long long per_plane = (long long)(g.Hb + 2) * g.Wh * quads;
     const long long total = 8 * per_plane;
     const T inf = Real<T>::inf();
     for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * kBlock) {
-        const long long plane = idx / per_plane, rem = idx % per_plane;
-        const int colour = (int)(plane / 4);
-        const int dp = (int)(rem % g.Dpad);
-        const long long px = rem / g.Dpad;
-        const int jc = (int)(px % g.Wh), il = (int)(px / g.Wh);
+        const int plane = (int)(idx / per_plane);
+        const long long rem = idx - plane * per_plane;
+        const int colour = plane / 4, slot = plane % 4;
+        const long long px = rem / quads;
+        const int dp = 4 * (int)(rem - px * quads);
+        const int il = (int)(px / g.Wh), jc = (int)(px - (long long)il * g.Wh);
         const int i = g.row0 + il - 1;
         const int j = 2 * jc + ((i + colour) & 1);
-        const int slot = (int)(plane % 4);
-        phi[g.plane_off[colour][slot] + (long long)il * g.row_stride + (long long)jc * g.Dpad + dp] =
-            (dp < g.D && dp <= j && j < g.W) ? T(0) : inf;
+        V4<T> v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v.v[k] = (dp + k < g.D && dp + k <= j && j < g.W) ? T(0) : inf;
+        store4(phi + g.plane_off[colour][slot] + (long long)il * g.row_stride + (long long)jc * g.Dpad + dp, v);
     }
 }
 
