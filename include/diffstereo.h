@@ -89,6 +89,15 @@ int ds_get_cost(ds_handle *h, uint8_t *out);
  * use ds_sweep). */
 int ds_iterate(ds_handle *h, int n_iters);
 
+/* The same n_iters calls of DiffusionGraph::diffusion_act, in the reference's own order:
+ * the raster loop of diffusion_graph.rs:264-269 (rows, then columns, vertex step + edge
+ * step at each pixel).  A pixel reads its left and top neighbours after, and its right and
+ * bottom neighbours before, their update of the iteration; all four lie on the neighbouring
+ * anti-diagonals, so the sweep runs one anti-diagonal i + j = k per launch, k ascending, and
+ * gives the sequential result (H + W - 1 small launches per iteration: the parity mode, not
+ * the fast one).  Synchronous at return.  Whole-image handles only. */
+int ds_iterate_raster(ds_handle *h, int n_iters);
+
 /* One colour's half-sweep (diffusion_act_vertexes + diffusion_act_edges,
  * diffusion_graph.rs:302-341, at every pixel of that colour) over the image rows
  * [row_begin, row_end), which must lie inside the handle's band.  Asynchronous:

@@ -465,6 +465,36 @@ __device__ __forceinline__ void st4_nt(float *p, const V4<float> &x)
 }
 __device__ __forceinline__ void st4_nt(double *p, const V4<double> &x) { store4(p, x); }
 
+// One pixel's update on the general path: any border, any number of valid labels.
+template <typename T, int LPP>
+__device__ __forceinline__ void update_pixel(const Geometry &g, T *phi, const uint8_t *cost_c, int colour,
+                                             const Pixel &p, const T lam[4], T lambda, int lseg, int lane)
+{
+    using R = Real<T>;
+    V4<T> psi[4], M[4];
+    load_psi(g, phi, 1 - colour, p, psi);
+    const V4<T> qc = load_cost<T>(cost_c, p);
+    messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
+    const int K = p.j < g.D - 1 ? p.j : g.D - 1;
+    V4<T> avg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        T acc = T(0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc += p.has[n] ? M[n].v[k] : T(0);
+        avg.v[k] = divide_by_neighbours(qc.v[k] + acc, p.nn);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        if (p.active && p.has[n] && p.d0 <= K) {  // d0 > K: the vector is +inf and stays so
+            V4<T> out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out.v[k] = (p.d0 + k <= K) ? avg.v[k] - M[n].v[k] : R::inf();
+            store4(phi + g.plane_off[colour][n] + p.own, out);
+        }
+    }
+}
+
 // PROBE only changes the kernel's name: launches made while ds_create times candidate
 // placements of phi show up apart from the real sweeps in a profile.
 template <typename T, int LPP, bool PROBE = false>
@@ -472,7 +502,6 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Geometry g, T *__restrict
                                                        const uint8_t *__restrict__ cost, T lambda,
                                                        int colour, int row_begin, int seg_pixels)
 {
-    using R = Real<T>;
     constexpr int PPW = 64 / LPP;
     constexpr int WAVES = kBlock / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -522,30 +551,35 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Geometry g, T *__restrict
                 st4_nt(dst[n] + off, out);
             }
         } else {
-            const Pixel p = locate(g, i, s, jc0 + q, d0);
-            load_psi(g, phi, 1 - colour, p, psi);
-            const V4<T> qc = load_cost<T>(cost_c, p);
-            messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
-            const int K = p.j < g.D - 1 ? p.j : g.D - 1;
-            V4<T> avg;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                T acc = T(0);
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc += p.has[n] ? M[n].v[k] : T(0);
-                avg.v[k] = divide_by_neighbours(qc.v[k] + acc, p.nn);
-            }
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (p.active && p.has[n] && d0 <= K) {  // d0 > K: the vector is +inf and stays so
-                    V4<T> out;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) out.v[k] = (d0 + k <= K) ? avg.v[k] - M[n].v[k] : R::inf();
-                    store4(phi + g.plane_off[colour][n] + p.own, out);
-                }
-            }
+            update_pixel<T, LPP>(g, phi, cost_c, colour, locate(g, i, s, jc0 + q, d0), lam, lambda, lseg, lane);
         }
     }
+}
+
+// The reference's raster order (diffusion_graph.rs:264-269), exactly: pixel (i, j) reads its
+// left and top neighbours after their update of this iteration and its right and bottom
+// neighbours before theirs.  All four lie on the anti-diagonals i + j -+ 1, so the pixels of
+// one anti-diagonal k = i + j are independent of one another, and launching the diagonals in
+// increasing k reproduces the sequential sweep.  One launch = one diagonal: pixels
+// (i_begin + m, k - i_begin - m), m < count, all of colour k & 1.
+template <typename T, int LPP>
+__global__ __launch_bounds__(kBlock) void sweep_diagonal_kernel(Geometry g, T *__restrict__ phi,
+                                                                const uint8_t *__restrict__ cost, T lambda,
+                                                                int k, int i_begin, int count)
+{
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    T lam[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
+    const int colour = k & 1;
+    const uint8_t *cost_c = cost + colour * g.cost_colour_stride;
+    const int m = (blockIdx.x * (kBlock / 64) + wave) * PPW + q;
+    const bool in_range = m < count;
+    const int i = in_range ? i_begin + m : i_begin;
+    const int j = in_range ? k - i : 2 * g.Wh + 1;  // past the last column: locate() marks it inactive
+    update_pixel<T, LPP>(g, phi, cost_c, colour, locate(g, i, j & 1, j >> 1, d0), lam, lambda, lseg, lane);
 }
 
 // ---- energy and residual ----------------------------------------------------------

@@ -29,6 +29,7 @@ SYMBOLS = {
     "ds_build_cost": (_I, [_P]),
     "ds_get_cost": (_I, [_P, _P]),
     "ds_iterate": (_I, [_P, _I]),
+    "ds_iterate_raster": (_I, [_P, _I]),
     "ds_sweep": (_I, [_P, _I, _I, _I]),
     "ds_energy": (_I, [_P, _DP, _DP]),
     "ds_labels": (_I, [_P, _I, _P]),
@@ -130,6 +131,10 @@ class DiffusionGraph:
     def iterate(self, n_iters):
         """n_iters x diffusion_act (diffusion_graph.rs:264-293) under the red-black schedule."""
         self._chk(lib().ds_iterate(self._h, int(n_iters)))
+
+    def iterate_raster(self, n_iters):
+        """n_iters x diffusion_act in the reference's raster order (anti-diagonal launches)."""
+        self._chk(lib().ds_iterate_raster(self._h, int(n_iters)))
 
     def sweep(self, colour, row_begin=None, row_end=None):
         self._chk(lib().ds_sweep(self._h, int(colour),

@@ -207,7 +207,7 @@ double DiffusionGraph::min_penalty_edge(std::size_t i, std::size_t j, std::size_
 void DiffusionGraph::diffusion_act()
 {
     push();
-    check(ds_iterate(h_, 1));
+    check(raster_order ? ds_iterate_raster(h_, 1) : ds_iterate(h_, 1));
     host_valid_ = false;
 }
 
@@ -222,7 +222,7 @@ void DiffusionGraph::diffusion(std::size_t first_iteration, std::size_t number_o
     for (std::size_t i = first_iteration; i < first_iteration + number_of_iterations; ++i) {
         if (verbose) std::printf("Iteration # %zu\n", i);
         const auto t0 = std::chrono::steady_clock::now();
-        check(ds_iterate(h_, 1));
+        check(raster_order ? ds_iterate_raster(h_, 1) : ds_iterate(h_, 1));
         const std::chrono::duration<double> dt = std::chrono::steady_clock::now() - t0;
         file << dt.count() << "s";
         if (verbose) std::printf("Energy: %.17g\n", energy());

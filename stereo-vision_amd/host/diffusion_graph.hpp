@@ -53,7 +53,10 @@ public:
     double min_penalty_edge(std::size_t i, std::size_t j, std::size_t n);                  // :480-494
 
     // Device operations.
-    void diffusion_act();                                                   // :264-293, red-black order
+    // false: red-black order (fast); true: the reference's raster order, exactly (one launch
+    // per anti-diagonal: slow, for checking results against the sequential implementation)
+    bool raster_order = false;
+    void diffusion_act();                                                   // :264-293
     void diffusion(std::size_t first_iteration, std::size_t number_of_iterations,
                    bool verbose = true);                                    // :349-368
     double energy();                                                        // :502-518

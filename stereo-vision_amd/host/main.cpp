@@ -4,13 +4,16 @@
 //
 //   stereovision LEFT.pgm RIGHT.pgm OUT.pgm [--max-disparity N] [--smoothing X]
 //                [--epsilon E] [--batch B] [--max-batches M] [--dtype f64|f32]
-//                [--decode crossing|crossing-host|belief] [--iterations K] [--quiet]
+//                [--decode crossing|crossing-host|belief] [--iterations K]
+//                [--schedule red-black|raster] [--quiet]
 //
 // --decode crossing (default) is the reference pipeline: diffusion batches on the GPU
 // until the epsilon-consistent sub-graph is non-empty (crossing out on the GPU too), then
 // the smallest surviving label per pixel.  --decode crossing-host keeps the reference's
 // vertex and edge masks on the host instead (O(H*W*D^2) bytes: small images only).
 // --decode belief runs --iterations diffusion iterations and takes the per-pixel argmin.
+// --schedule raster sweeps in the reference's sequential order (same results as its
+// CPU implementation up to rounding; one small launch per anti-diagonal, so slower).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,7 +35,7 @@ int main(int argc, char **argv)
     std::size_t max_disparity = 40, batch = 200, max_batches = 1000, iterations = 200;
     double smoothing = 1.2, epsilon = -1.;
     int dtype = DS_F64;
-    bool crossing = true, host_masks = false, verbose = true;
+    bool crossing = true, host_masks = false, verbose = true, raster = false;
     for (int a = 4; a < argc; ++a) {
         const std::string o = argv[a];
         auto need = [&](const char *name) -> const char * {
@@ -58,6 +61,14 @@ int main(int argc, char **argv)
             crossing = mode != "belief";
             host_masks = mode == "crossing-host";
         }
+        else if (o == "--schedule") {
+            const std::string mode = need("--schedule");
+            if (mode != "raster" && mode != "red-black") {
+                std::fprintf(stderr, "unknown --schedule %s\n", mode.c_str());
+                return 2;
+            }
+            raster = mode == "raster";
+        }
         else if (o == "--quiet") verbose = false;
         else {
             std::fprintf(stderr, "unknown option %s\n", o.c_str());
@@ -72,6 +83,7 @@ int main(int argc, char **argv)
         if (epsilon < 0.) epsilon = 1. / double(10 * left.width * left.height);
         std::printf("Epsilon: %g\n", epsilon);
         DiffusionGraph graph = DiffusionGraph::initialize(left.matrix, right.matrix, max_disparity, smoothing, dtype);
+        graph.raster_order = raster;
         Matrix disparity_map;
         if (crossing) {
             CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph), !host_masks);

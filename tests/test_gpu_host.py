@@ -42,6 +42,23 @@ def test_cli_reference_pipeline_on_bundled_pair(tmp_path, golden_dir, dtype, dec
     assert float(np.mean(m.astype(np.int32) == gold["labels_seq"])) >= 0.995
 
 
+def test_cli_raster_schedule_reproduces_sequential_run(tmp_path, golden_dir):
+    """--schedule raster: the same number of batches, the same map and (with --decode belief)
+    the same labels as the sequential golden run."""
+    gold = np.load(os.path.join(golden_dir, "bundled_main.npz"))
+    out_pgm = tmp_path / "raster.pgm"
+    run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
+                          os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--schedule", "raster"],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "%d iterations of diffusion ended" % int(gold["iters_seq"]) in run.stdout
+    assert "Graph is consistent. Diffusion is done" in run.stdout
+    m, _, _ = pyoracle.pgm_reader(str(out_pgm))
+    assert np.array_equal(m.astype(np.int32), gold["labels_seq"])
+    last_energy = [ln for ln in run.stdout.splitlines() if ln.startswith("Energy: ")][-1]
+    assert abs(float(last_energy.split()[1]) - float(gold["energy_seq"])) <= 1e-9 * abs(float(gold["energy_seq"]))
+
+
 def test_cli_belief_decode(tmp_path, golden_dir):
     gold = np.load(os.path.join(golden_dir, "bundled_seq_100.npz"))
     out_pgm = tmp_path / "belief.pgm"

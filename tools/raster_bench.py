@@ -1,0 +1,19 @@
+"""Time ds_iterate_raster (anti-diagonal launches) against ds_iterate.  env: H, W, D, DTYPE."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from stereo_vision_amd import diffstereo, synth  # noqa: E402
+
+H, W, D = (int(os.environ.get(k, v)) for k, v in (("H", 2160), ("W", 3840), ("D", 256)))
+left, right, _ = synth.synthetic_pair(H, W, D)
+g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=os.environ.get("DTYPE", "f32"))
+for name, fn in (("red-black", g.iterate), ("raster", g.iterate_raster)):
+    fn(1)
+    t0 = time.perf_counter()
+    fn(3)
+    print("%s: %.2f ms per iteration" % (name, (time.perf_counter() - t0) / 3 * 1e3), flush=True)
