@@ -129,6 +129,23 @@ int ds_labels(ds_handle *h, int mode, uint32_t *out);
 int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
                     int *not_empty, int *passes);
 
+/* The same computation in steps, for row bands (one handle per band; the halos of phi must be
+ * current, as after ds_sweep + exchange):
+ *   ds_co_begin   vertex masks and pair minima of the band's pixels (initialize_with_epsilon);
+ *   ds_co_halo    device pointer / size of a mask halo row, same side / which meaning as
+ *                 ds_halo: after ds_co_begin and after every pass, a band sends its first and
+ *                 last row's masks (both colours) to the bands above / below;
+ *   ds_co_pass    one relaxation pass over the band; *changed: a vertex died, *lost: a pixel
+ *                 has no vertex left.  The caller ORs both over all bands; it stops when no
+ *                 band changed, or when any band lost a pixel (the closure is then empty: the
+ *                 pixel grid is connected);
+ *   ds_co_finish  empty != 0 clears the band's masks (the early stop above); then labels /
+ *                 alive_out / *not_empty of the band's rows as in ds_crossing_out. */
+int ds_co_begin(ds_handle *h, double epsilon);
+int ds_co_pass(ds_handle *h, int *changed, int *lost);
+int ds_co_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_t *bytes);
+int ds_co_finish(ds_handle *h, int empty, uint32_t *labels, uint8_t *alive_out, int *not_empty);
+
 /* Replace direct access to the public field `potentials` (diffusion_graph.rs:43).
  * Rows [row_begin, row_end) may include the band's halo rows. */
 int ds_get_phi_rows(ds_handle *h, int row_begin, int row_end, void *out);

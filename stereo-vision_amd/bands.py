@@ -79,6 +79,36 @@ class HipBandEngine:
     def energy(self):
         return self.g.energy()
 
+    # crossing-out: the mask halo rows travel like the phi halo rows
+    def co_begin(self, epsilon):
+        self.g.co_begin(epsilon)
+        self._co_views = {}
+
+    def co_pass(self):
+        return self.g.co_pass()
+
+    def _co_view(self, colour, side, which):
+        key = (colour, side, which)
+        if key not in self._co_views:
+            ptr, nbytes = self.g.co_halo(colour, side, which)
+            self._co_views[key] = torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
+        return self._co_views[key]
+
+    def co_send_buffer(self, colour, side):
+        v = self._co_view(colour, side, 0)
+        return v.cpu() if self.stage else v
+
+    def co_recv_buffer(self, colour, side):
+        v = self._co_view(colour, side, 1)
+        return torch.empty(v.shape, dtype=v.dtype) if self.stage else v
+
+    def co_commit_recv(self, colour, side, buf):
+        if self.stage:
+            self._co_view(colour, side, 1).copy_(buf)
+
+    def co_finish(self, empty, with_mask=False):
+        return self.g.co_finish(empty, with_mask)
+
     def synchronize(self):
         torch.cuda.current_stream().synchronize()
 
@@ -139,6 +169,56 @@ class BandRunner:
                 r.wait()
             for side, buf in recvs:
                 self.e.commit_recv(colour, side, buf)
+
+    def _reduce_flags(self, values, op):
+        t = torch.tensor([int(v) for v in values], dtype=torch.int32)
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=op, group=self.group)
+        return [bool(v) for v in t.tolist()]
+
+    def _co_exchange(self):
+        if self.world == 1:
+            return
+        e = self.e
+        e.synchronize()
+        ops, recvs = [], []
+        for colour in (0, 1):
+            for side, peer in ((0, self.up), (1, self.down)):
+                if peer is None:
+                    continue
+                ops.append(dist.P2POp(dist.isend, e.co_send_buffer(colour, side), peer, self.group))
+                rb = e.co_recv_buffer(colour, side)
+                recvs.append((colour, side, rb))
+                ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
+        for r in (dist.batch_isend_irecv(ops) if ops else []):
+            r.wait()
+        for colour, side, buf in recvs:
+            e.co_commit_recv(colour, side, buf)
+
+    def crossing_out(self, epsilon, max_passes=1 << 30, with_mask=False):
+        """CrossingOutGraph::initialize_with_epsilon + crossing_out + simple_best_labeling
+        (crossing_out_graph.rs:67-183,307-327) over all bands.  Every band relaxes its rows,
+        the boundary rows' masks go to the neighbouring bands, and the two flags (a vertex
+        died / a pixel has no vertex left) are OR-ed over the ranks.  Returns this band's
+        labels (and mask), the global not_empty and the number of passes."""
+        e = self.e
+        e.co_begin(epsilon)
+        self._co_exchange()
+        passes = 0
+        while True:
+            changed, lost = self._reduce_flags(e.co_pass(), dist.ReduceOp.MAX)
+            passes += 1
+            if lost or not changed:
+                break
+            if passes >= max_passes:
+                raise RuntimeError("crossing out did not reach its fixed point within max_passes")
+            self._co_exchange()
+        out = e.co_finish(lost, with_mask)
+        out["not_empty"] = self._reduce_flags([out["not_empty"]], dist.ReduceOp.MIN)[0]
+        out["passes"] = passes
+        return out
 
     def energy(self):
         """Energy of the whole image (diffusion_graph.rs:502-518): sum over bands."""

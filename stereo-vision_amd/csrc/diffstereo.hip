@@ -56,6 +56,8 @@ struct ds_handle {
     void *co_gmin = nullptr;                          // [2][Hb][Wh][4] min edge penalty per (pixel, slot)
     uint8_t *co_host_order = nullptr;                 // [Hb][W][D], only when the mask is asked for
     int *co_flags = nullptr;                          // [0] changed, [1] some pixel empty
+    double co_epsilon = 0.0;
+    bool co_begun = false;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
 
@@ -767,17 +769,14 @@ int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_beg
     return DS_OK;
 }
 
-int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
-                    int *not_empty, int *passes)
+int ds_co_begin(ds_handle *h, double epsilon)
 {
     if (!h) return DS_ERR_ARG;
-    if (!(epsilon >= 0.0) || max_passes < 1) return fail(h, DS_ERR_ARG, "epsilon must be >= 0 and max_passes >= 1");
+    if (!(epsilon >= 0.0)) return fail(h, DS_ERR_ARG, "epsilon must be >= 0");
     const ds::Geometry &g = h->g;
-    if (g.row0 != 0 || g.Hb != g.H)
-        return fail(h, DS_ERR_STATE, "ds_crossing_out needs the whole image (bands would need a mask halo exchange)");
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
-    const size_t mask_bytes = (size_t)(2 * g.cost_colour_stride);
+    const size_t mask_bytes = (size_t)(2 * ds::mask_colour_stride(g));
     if (!h->co_alive) {
         hipError_t e = hipMalloc(&h->co_alive, mask_bytes);
         if (e == hipSuccess) e = hipMalloc(&h->co_gmin, (size_t)2 * g.Hb * g.Wh * 4 * h->elem);
@@ -786,14 +785,18 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
             return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP,
                         std::string("hipMalloc(crossing-out state): ") + hipGetErrorString(e));
     }
-    if (alive_out && !h->co_host_order) {
-        hipError_t e = hipMalloc(&h->co_host_order, (size_t)g.Hb * g.W * g.D);
-        if (e != hipSuccess)
-            return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP,
-                        std::string("hipMalloc(mask copy): ") + hipGetErrorString(e));
-    }
+    h->co_epsilon = epsilon;
+    h->co_begun = true;
     const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
     HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
+    // Halo rows start all-alive: until the neighbouring band's rows arrive they must not
+    // take support away (deletions cannot be undone; a late deletion only costs a pass).
+    const size_t row_bytes = (size_t)g.Wh * g.Dpad;
+    for (int colour = 0; colour < 2; ++colour) {
+        uint8_t *base = h->co_alive + colour * ds::mask_colour_stride(g);
+        HIPCHK(h, hipMemsetAsync(base, 1, row_bytes, h->stream));
+        HIPCHK(h, hipMemsetAsync(base + (size_t)(g.Hb + 1) * row_bytes, 1, row_bytes, h->stream));
+    }
     for (int colour = 0; colour < 2; ++colour) {
         rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
@@ -805,34 +808,67 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
         if (rc != DS_OK) return rc;
         HIPCHK(h, hipGetLastError());
     }
-    int done = 0, host_flags[2] = {0, 0};
-    bool fixed = false;
-    while (done < max_passes && !fixed) {
-        HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
-        for (int colour = 0; colour < 2; ++colour) {
-            rc = dispatch(h, [&](auto t, auto lpp) -> int {
-                using T = decltype(t);
-                hipLaunchKernelGGL((ds::co_relax_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
-                                   static_cast<const T *>(h->phi), (T)h->lambda, (T)epsilon, colour, h->seg_pixels,
-                                   h->co_alive, static_cast<const T *>(h->co_gmin), h->co_flags);
-                return DS_OK;
-            });
-            if (rc != DS_OK) return rc;
-            HIPCHK(h, hipGetLastError());
-        }
-        HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        ++done;
-        fixed = host_flags[0] == 0;
-        if (host_flags[1] && g.H * g.W > 1) {
-            // A pixel without alive vertices takes all support from its neighbours, they from
-            // theirs, and the pixel grid is connected: the greatest consistent sub-graph is
-            // empty.  Skip the passes that would spread that over the image.
-            HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
-            fixed = true;
-        }
+    return DS_OK;
+}
+
+int ds_co_pass(ds_handle *h, int *changed, int *lost)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!changed || !lost) return fail(h, DS_ERR_ARG, "changed / lost is NULL");
+    if (!h->co_begun) return fail(h, DS_ERR_STATE, "ds_co_pass before ds_co_begin");
+    const ds::Geometry &g = h->g;
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
+    HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
+    for (int colour = 0; colour < 2; ++colour) {
+        rc = dispatch(h, [&](auto t, auto lpp) -> int {
+            using T = decltype(t);
+            hipLaunchKernelGGL((ds::co_relax_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
+                               static_cast<const T *>(h->phi), (T)h->lambda, (T)h->co_epsilon, colour,
+                               h->seg_pixels, h->co_alive, static_cast<const T *>(h->co_gmin), h->co_flags);
+            return DS_OK;
+        });
+        if (rc != DS_OK) return rc;
+        HIPCHK(h, hipGetLastError());
     }
-    if (!fixed) return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
+    int host_flags[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *changed = host_flags[0];
+    *lost = host_flags[1];
+    return DS_OK;
+}
+
+int ds_co_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_t *bytes)
+{
+    if (!h) return DS_ERR_ARG;
+    if ((colour | 1) != 1 || (side | 1) != 1 || (which | 1) != 1 || !dev_ptr || !bytes)
+        return fail(h, DS_ERR_ARG, "bad ds_co_halo argument");
+    if (!h->co_begun) return fail(h, DS_ERR_STATE, "ds_co_halo before ds_co_begin");
+    const ds::Geometry &g = h->g;
+    // rows of the mask buffer: 0 = halo above, 1..Hb = the band, Hb + 1 = halo below
+    const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
+    *dev_ptr = h->co_alive + colour * ds::mask_colour_stride(g) + (long long)il * g.Wh * g.Dpad;
+    *bytes = (size_t)g.Wh * g.Dpad;
+    return DS_OK;
+}
+
+int ds_co_finish(ds_handle *h, int empty, uint32_t *labels, uint8_t *alive_out, int *not_empty)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!h->co_begun) return fail(h, DS_ERR_STATE, "ds_co_finish before ds_co_begin");
+    const ds::Geometry &g = h->g;
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    if (alive_out && !h->co_host_order) {
+        hipError_t e = hipMalloc(&h->co_host_order, (size_t)g.Hb * g.W * g.D);
+        if (e != hipSuccess)
+            return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP,
+                        std::string("hipMalloc(mask copy): ") + hipGetErrorString(e));
+    }
+    const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
+    if (empty) HIPCHK(h, hipMemsetAsync(h->co_alive, 0, (size_t)(2 * ds::mask_colour_stride(g)), h->stream));
     HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
     for (int colour = 0; colour < 2; ++colour) {
         switch (h->lpp) {
@@ -842,6 +878,7 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
         }
         HIPCHK(h, hipGetLastError());
     }
+    int host_flags[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (labels)
         HIPCHK(h, hipMemcpyAsync(labels, h->d_labels, (size_t)g.Hb * g.W * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -854,6 +891,32 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (not_empty) *not_empty = host_flags[1] == 0;
+    return DS_OK;
+}
+
+int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
+                    int *not_empty, int *passes)
+{
+    if (!h) return DS_ERR_ARG;
+    if (max_passes < 1) return fail(h, DS_ERR_ARG, "max_passes must be >= 1");
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H)
+        return fail(h, DS_ERR_STATE,
+                    "ds_crossing_out needs the whole image; bands use ds_co_begin / ds_co_pass / ds_co_halo / ds_co_finish");
+    int rc = ds_co_begin(h, epsilon);
+    if (rc != DS_OK) return rc;
+    int done = 0, changed = 1, lost = 0;
+    while (done < max_passes && changed && !lost) {
+        rc = ds_co_pass(h, &changed, &lost);
+        if (rc != DS_OK) return rc;
+        ++done;
+    }
+    if (changed && !lost) return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
+    // A pixel without alive vertices takes all support from its neighbours, they from theirs,
+    // and the pixel grid is connected: the greatest consistent sub-graph is empty.  That ends
+    // the loop early; ds_co_finish clears the masks instead of the passes that would have.
+    rc = ds_co_finish(h, lost, labels, alive_out, not_empty);
+    if (rc != DS_OK) return rc;
     if (passes) *passes = done;
     return DS_OK;
 }

@@ -788,12 +788,23 @@ __global__ __launch_bounds__(kBlock) void labels_kernel(Geometry g, const T *__r
 // edge to an alive label of t'" is one more min-plus product: with psi restricted to the
 // neighbour's alive labels (+inf elsewhere),
 //     exists d': usable  <=>  phi[t][n][d] + min_{d' alive} (lambda|d-d'| + psi(d')) <= gmin + eps
-// evaluated with the same scans as the sweep.  Masks use the packed cost's layout
-// alive[colour][row][jc][dp] (one byte per label, a dword per lane).
+// evaluated with the same scans as the sweep.  Masks hold one byte per label, a dword per lane.
 template <typename T> __device__ __forceinline__ V4<T> load_own(const Geometry &g, const T *phi, int colour,
                                                                 const Pixel &p, int n)
 {
     return (p.active && p.has[n]) ? load4(phi + g.plane_off[colour][n] + p.own) : splat(T(0));
+}
+
+// Masks are stored like the packed cost plus one halo row above and below each colour's
+// rows (a band reads its neighbours' boundary rows there): alive[colour][Hb + 2][Wh][Dpad].
+// mask_base() points at band row 0 of a colour, so Pixel::cost offsets apply unchanged.
+__host__ __device__ __forceinline__ long long mask_colour_stride(const Geometry &g)
+{
+    return (long long)(g.Hb + 2) * g.Wh * g.Dpad;
+}
+template <typename P> __device__ __forceinline__ P *mask_base(const Geometry &g, P *alive, int colour)
+{
+    return alive + colour * mask_colour_stride(g) + (long long)g.Wh * g.Dpad;
 }
 
 __device__ __forceinline__ long long mask_off(const Geometry &g, const Pixel &p, int n)
@@ -828,7 +839,7 @@ __global__ __launch_bounds__(kBlock) void co_init_kernel(Geometry g, const T *__
 #pragma unroll
     for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
     const uint8_t *cost_c = cost + colour * g.cost_colour_stride;
-    uint8_t *alive_c = alive + colour * g.cost_colour_stride;
+    uint8_t *alive_c = mask_base(g, alive, colour);
     T *gmin_c = gmin + (long long)colour * g.Hb * g.Wh * 4;
 
     const int seg0 = blockIdx.x * seg_pixels;
@@ -893,8 +904,8 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
     T lam[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
-    uint8_t *alive_c = alive + colour * g.cost_colour_stride;
-    const uint8_t *alive_o = alive + (1 - colour) * g.cost_colour_stride;
+    uint8_t *alive_c = mask_base(g, alive, colour);
+    const uint8_t *alive_o = mask_base(g, alive, 1 - colour);
     const T *gmin_c = gmin + (long long)colour * g.Hb * g.Wh * 4;
 
     const int seg0 = blockIdx.x * seg_pixels;
@@ -957,7 +968,7 @@ __global__ __launch_bounds__(kBlock) void co_labels_kernel(Geometry g, const uin
     const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
     const int i = g.row0 + blockIdx.y;
     const int s = (i + colour) & 1;
-    const uint8_t *alive_c = alive + colour * g.cost_colour_stride;
+    const uint8_t *alive_c = mask_base(g, alive, colour);
     const int seg0 = blockIdx.x * seg_pixels;
     const int groups = seg_pixels / PPW;
     for (int grp = wave; grp < groups; grp += kBlock / 64) {
@@ -991,7 +1002,7 @@ __global__ __launch_bounds__(kBlock) void co_unpack_kernel(Geometry g, const uin
         const long long px = idx / g.D;
         const int j = (int)(px % g.W), r = (int)(px / g.W);
         const int colour = (g.row0 + r + j) & 1;
-        out[idx] = alive[colour * g.cost_colour_stride + ((long long)r * g.Wh + (j >> 1)) * g.Dpad + d] & 1u;
+        out[idx] = mask_base(g, alive, colour)[((long long)r * g.Wh + (j >> 1)) * g.Dpad + d] & 1u;
     }
 }
 

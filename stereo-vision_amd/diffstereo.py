@@ -34,6 +34,10 @@ SYMBOLS = {
     "ds_energy": (_I, [_P, _DP, _DP]),
     "ds_labels": (_I, [_P, _I, _P]),
     "ds_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
+    "ds_co_begin": (_I, [_P, _D]),
+    "ds_co_pass": (_I, [_P, _IP, _IP]),
+    "ds_co_halo": (_I, [_P, _I, _I, _I, _PP, C.POINTER(C.c_size_t)]),
+    "ds_co_finish": (_I, [_P, _I, _P, _P, _IP]),
     "ds_get_phi_rows": (_I, [_P, _I, _I, _P]),
     "ds_set_phi_rows": (_I, [_P, _I, _I, _P]),
     "ds_get_phi": (_I, [_P, _P]),
@@ -160,6 +164,31 @@ class DiffusionGraph:
         self._chk(lib().ds_crossing_out(self._h, float(epsilon), int(max_passes), _ptr(labels),
                                         _ptr(alive) if with_mask else None, C.byref(ne), C.byref(n)))
         out = {"labels": labels, "not_empty": bool(ne.value), "passes": n.value}
+        if with_mask:
+            out["alive"] = alive
+        return out
+
+    # crossing-out in steps (row bands; see include/diffstereo.h)
+    def co_begin(self, epsilon):
+        self._chk(lib().ds_co_begin(self._h, float(epsilon)))
+
+    def co_pass(self):
+        ch, lo = C.c_int(), C.c_int()
+        self._chk(lib().ds_co_pass(self._h, C.byref(ch), C.byref(lo)))
+        return bool(ch.value), bool(lo.value)
+
+    def co_halo(self, colour, side, which):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(lib().ds_co_halo(self._h, colour, side, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def co_finish(self, empty, with_mask=False):
+        labels = np.empty((self.rows, self.W), dtype=np.uint32)
+        alive = np.empty((self.rows, self.W, self.D), dtype=np.uint8) if with_mask else None
+        ne = C.c_int()
+        self._chk(lib().ds_co_finish(self._h, int(bool(empty)), _ptr(labels),
+                                     _ptr(alive) if with_mask else None, C.byref(ne)))
+        out = {"labels": labels, "not_empty": bool(ne.value)}
         if with_mask:
             out["alive"] = alive
         return out

@@ -5,7 +5,9 @@ poisoned with NaN, so any read outside band + halo shows up in the result."""
 import numpy as np
 import torch
 
+from oracle import pyoracle
 from oracle.pyoracle import FastOracle
+from tests.util import NumpyCrossingOut
 
 
 class OracleBandEngine:
@@ -46,6 +48,39 @@ class OracleBandEngine:
 
     def synchronize(self):
         pass
+
+    # crossing-out on the band (tests/util.NumpyCrossingOut), masks of the halo rows exchanged
+    def co_begin(self, epsilon):
+        cost = pyoracle.cost_volume(self.f.L, self.f.R, self.D).astype(np.float64).transpose(1, 2, 0)
+        with np.errstate(invalid="ignore"):  # poisoned rows outside band + halo
+            self.co = NumpyCrossingOut(self.f.potentials, cost, self.f.lam, epsilon, self.row_begin, self.row_end)
+        lo, hi = max(self.row_begin - 1, 0), min(self.row_end + 1, self.H)
+        self.co.alive[:lo] = False   # anything read beyond the halo rows would kill support
+        self.co.alive[hi:] = False
+
+    def co_pass(self):
+        return self.co.relax()
+
+    def co_send_buffer(self, colour, side):
+        row = self.row_begin if side == 0 else self.row_end - 1
+        return torch.from_numpy(self.co.alive[row, self._cols(row, colour), :].astype(np.uint8))
+
+    def co_recv_buffer(self, colour, side):
+        row = self.row_begin - 1 if side == 0 else self.row_end
+        return torch.empty((len(self._cols(row, colour)), self.D), dtype=torch.uint8)
+
+    def co_commit_recv(self, colour, side, buf):
+        row = self.row_begin - 1 if side == 0 else self.row_end
+        self.co.alive[row, self._cols(row, colour), :] = buf.numpy().astype(bool)
+
+    def co_finish(self, empty, with_mask=False):
+        band = slice(self.row_begin, self.row_end)
+        if empty:
+            self.co.alive[band] = False
+        out = {"labels": self.co.labels(), "not_empty": bool(self.co.alive[band].any(axis=2).all())}
+        if with_mask:
+            out["alive"] = self.co.alive[band].astype(np.uint8)
+        return out
 
 
 def _row_energy(f, i):

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 from __graft_entry__ import load_package
 from oracle.pyoracle import FastOracle
 from tests.band_oracle_engine import OracleBandEngine
-from tests.util import random_pair, random_phi
+from tests.util import NumpyCrossingOut, random_pair, random_phi
 
 load_package()
 from stereo_vision_amd import bands  # noqa: E402
@@ -77,3 +77,43 @@ def test_bands_over_gloo_match_single_process(world, H):
     assert len(out) == world
     for rank in range(world):
         assert out[rank] == (True, True, True), "rank %d: %s" % (rank, out[rank])
+
+
+def _co_worker(rank, world, port, H, W, D, iters, eps, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyoracle
+        left, right = random_pair(H, W, seed=21)
+        rb, re = bands.partition_rows(H, world)[rank]
+        eng = OracleBandEngine(left, right, D, 1.2, rb, re)
+        eng.set_rows(np.zeros((H, W, 4, D)), rb, re)
+        runner = bands.BandRunner(eng)
+        runner.exchange_all()
+        runner.iterate(iters)
+        got = runner.crossing_out(eps, with_mask=True)
+        ref = FastOracle(left, right, D, 1.2)
+        ref.iterate(iters)
+        cost = pyoracle.cost_volume(left, right, D).astype(np.float64).transpose(1, 2, 0)
+        whole = NumpyCrossingOut(ref.potentials, cost, 1.2, eps)
+        want = whole.run()
+        out[rank] = (bool(np.array_equal(got["alive"].astype(bool), want[rb:re])),
+                     got["not_empty"] == bool(want.any(axis=2).all()),
+                     bool(np.array_equal(got["labels"], whole.labels()[rb:re])), got["passes"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,iters,eps", [(2, 9, 30, 5.0), (3, 7, 30, 20.0), (4, 4, 2, 60.0), (2, 6, 2, 3.0)])
+def test_crossing_out_over_bands_matches_whole_image(world, H, iters, eps):
+    """BandRunner.crossing_out: mask halo exchange + OR-ed flags give every band exactly its
+    rows of the whole image's greatest consistent sub-graph (non-empty and empty outcomes)."""
+    W, D = 10, 6
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_co_worker, args=(world, _free_port(), H, W, D, iters, eps, out), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        assert out[rank][:3] == (True, True, True), "rank %d: %s" % (rank, out[rank])
+    assert len({out[r][3] for r in range(world)}) == 1  # every rank ran the same number of passes

@@ -51,7 +51,16 @@ def _worker(rank, world, port, dtype, out):
         e_ok = abs(energy - e_ref) <= 1e-9 * max(1.0, abs(e_ref))
         if not (same and e_ok):
             print("rank", rank, "phi same:", same, "energy", energy, "ref", e_ref, flush=True)
-        out[rank] = (bool(same), bool(e_ok))
+        # the reference's stopping rule over the bands: crossing-out with exchanged mask halos
+        co_ok = True
+        for eps in (4.0, 40.0):
+            got = runner.crossing_out(eps, with_mask=True)
+            want = whole.crossing_out(eps, with_mask=True)
+            co_ok = co_ok and np.array_equal(got["alive"], want["alive"][rb:re]) \
+                and np.array_equal(got["labels"], want["labels"][rb:re]) and got["not_empty"] == want["not_empty"]
+        if not co_ok:
+            print("rank", rank, "crossing-out differs", flush=True)
+        out[rank] = (bool(same), bool(e_ok and co_ok))
         g.close()
         whole.close()
     finally:

@@ -13,7 +13,7 @@ import pytest
 from __graft_entry__ import load_package
 from oracle import pyoracle
 from oracle.pyoracle import OracleGraph
-from tests.util import random_pair, random_phi
+from tests.util import NumpyCrossingOut, random_pair, random_phi
 
 pytestmark = pytest.mark.gpu
 
@@ -89,58 +89,8 @@ def test_empty_graph_and_band_refusal():
     g.close()
     band = diffstereo.DiffusionGraph(left, right, 6, 1.2, row_begin=1, row_end=3)
     with pytest.raises(diffstereo.DiffStereoError):
-        band.crossing_out(0.1)
+        band.crossing_out(0.1)  # a band goes through co_begin / co_pass / co_halo / co_finish
     band.close()
-
-
-def numpy_closure(phi, cost, lam, eps):
-    """Vectorised restatement of initialize_with_epsilon + crossing_out
-    (crossing_out_graph.rs:67-183) with explicit [H][W][D][D] edge tables per slot."""
-    H, W, _, D = phi.shape
-    jj = np.arange(W)[None, :, None]
-    dd = np.arange(D)
-    valid = np.broadcast_to(dd[None, None, :] <= jj, (H, W, D)).copy()
-    has = np.zeros((H, W, 4), bool)
-    has[:, 1:, 0] = True
-    has[1:, :, 1] = True
-    has[:, :-1, 2] = True
-    has[:-1, :, 3] = True
-    f = cost - (phi * has[..., None]).sum(axis=2)
-    fmin = np.where(valid, f, np.inf).min(axis=2, keepdims=True)
-    alive = valid & (f <= fmin + eps)
-    shift = {0: (0, -1), 1: (-1, 0), 2: (0, 1), 3: (1, 0)}
-
-    def neighbour(a, n, fill):
-        di, dj = shift[n]
-        out = np.full_like(a, fill)
-        src = a[max(di, 0):H - max(-di, 0), max(dj, 0):W - max(-dj, 0)]
-        out[max(-di, 0):H - max(di, 0), max(-dj, 0):W - max(dj, 0)] = src  # out[i][j] = a[i+di][j+dj]
-        return out
-
-    usable = []
-    for n in range(4):
-        psi = neighbour(phi[:, :, n ^ 2, :], n, np.inf)
-        nvalid = neighbour(valid, n, False)
-        e = lam * np.abs(dd[:, None] - dd[None, :])[None, None] + phi[:, :, n, :, None] + psi[:, :, None, :]
-        ok = valid[:, :, :, None] & nvalid[:, :, None, :]
-        if n == 2:
-            ok = ok & (dd[None, :] <= dd[:, None] + 1)[None, None]
-        if n == 0:
-            ok = ok & (dd[:, None] <= dd[None, :] + 1)[None, None]
-        e = np.where(ok, e, np.inf)
-        mn = e.reshape(H, W, -1).min(axis=2)[:, :, None, None]
-        usable.append(ok & (e <= mn + eps))
-    passes = 0
-    while True:
-        passes += 1
-        nxt = alive.copy()
-        for n in range(4):
-            partner = neighbour(alive, n, False)
-            support = (usable[n] & partner[:, :, None, :]).any(axis=3)
-            nxt &= support | ~has[:, :, n, None]
-        if np.array_equal(nxt, alive):
-            return alive
-        alive = nxt
 
 
 def test_f32_and_large_masks_are_consistent():
@@ -157,7 +107,7 @@ def test_f32_and_large_masks_are_consistent():
         alive = r["alive"].astype(bool)
         phi = g.get_phi().astype(np.float64)
         cost = g.get_cost().astype(np.float64).transpose(1, 2, 0)  # [H][W][D]
-        want = numpy_closure(phi, cost, 1.2, eps)
+        want = NumpyCrossingOut(phi, cost, 1.2, eps).run()
         if dtype == "f64":
             assert np.array_equal(alive, want)
         else:  # f32 thresholds are evaluated in f32: allow a handful of borderline labels
@@ -168,3 +118,51 @@ def test_f32_and_large_masks_are_consistent():
             lab = r["labels"].astype(np.int64)
             assert (lab <= np.minimum(np.arange(W)[None, :], D - 1)).all()
         g.close()
+
+
+@pytest.mark.parametrize("iters,eps", [(30, 5.0), (2, 60.0), (2, 3.0)])
+def test_bands_on_one_gpu_match_whole_image(iters, eps):
+    """Three band handles in one process, phi and mask halo rows copied device to device
+    through ds_halo / ds_co_halo: every band ends with its rows of the whole image's result."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    H, W, D = 11, 18, 12
+    left, right = random_pair(H, W, seed=5)
+    whole = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f64")
+    cuts = [(0, 4), (4, 5), (5, 11)]
+    bands = [diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f64", row_begin=a, row_end=b) for a, b in cuts]
+
+    def exchange(halo):
+        for up, down in zip(bands[:-1], bands[1:]):
+            for src, dst in (((up, 1, 0), (down, 0, 1)), ((down, 0, 0), (up, 1, 1))):
+                for colour in (0, 1):
+                    sp, n = getattr(src[0], halo)(colour, src[1], src[2])
+                    dp, m = getattr(dst[0], halo)(colour, dst[1], dst[2])
+                    assert n == m
+                    src[0].synchronize()
+                    assert hip.hipMemcpy(C.c_void_p(dp), C.c_void_p(sp), C.c_size_t(n), 3) == 0
+
+    for _ in range(iters):
+        for colour in (0, 1):
+            whole.sweep(colour)
+            for b in bands:
+                b.sweep(colour)
+            exchange("halo")
+    want = whole.crossing_out(eps, with_mask=True)
+    for b in bands:
+        b.co_begin(eps)
+    exchange("co_halo")
+    while True:
+        flags = [b.co_pass() for b in bands]
+        changed, lost = any(f[0] for f in flags), any(f[1] for f in flags)
+        if lost or not changed:
+            break
+        exchange("co_halo")
+    got = [b.co_finish(lost, with_mask=True) for b in bands]
+    assert np.array_equal(np.concatenate([g["alive"] for g in got]), want["alive"])
+    assert np.array_equal(np.concatenate([g["labels"] for g in got]), want["labels"])
+    assert all(g["not_empty"] for g in got) == want["not_empty"]
+    with pytest.raises(diffstereo.DiffStereoError):
+        diffstereo.DiffusionGraph(left, right, D, 1.2).co_pass()  # before co_begin
+    for b in bands + [whole]:
+        b.close()
