@@ -32,7 +32,7 @@ def test_cli_reference_pipeline_on_bundled_pair(tmp_path, golden_dir, dtype, dec
     run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
                           os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--dtype", dtype, "--decode", decode,
                           "--quiet"],
-                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+                         capture_output=True, text=True, timeout=100, cwd=str(tmp_path))
     assert run.returncode == 0, run.stdout + run.stderr
     assert "Disparity map is consistent: true" in run.stdout
     m, w, h = pyoracle.pgm_reader(str(out_pgm))
@@ -49,7 +49,7 @@ def test_cli_raster_schedule_reproduces_sequential_run(tmp_path, golden_dir):
     out_pgm = tmp_path / "raster.pgm"
     run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
                           os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--schedule", "raster"],
-                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+                         capture_output=True, text=True, timeout=100, cwd=str(tmp_path))
     assert run.returncode == 0, run.stdout + run.stderr
     assert "%d iterations of diffusion ended" % int(gold["iters_seq"]) in run.stdout
     assert "Graph is consistent. Diffusion is done" in run.stdout
@@ -65,7 +65,7 @@ def test_cli_belief_decode(tmp_path, golden_dir):
     run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
                           os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--decode", "belief",
                           "--iterations", "100", "--quiet"],
-                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+                         capture_output=True, text=True, timeout=100, cwd=str(tmp_path))
     assert run.returncode == 0, run.stdout + run.stderr
     m, _, _ = pyoracle.pgm_reader(str(out_pgm))
     assert np.array_equal(m.astype(np.int32), gold["belief_labels"])

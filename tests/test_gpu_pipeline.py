@@ -1,0 +1,67 @@
+"""stereo-vision_amd/pipeline.py on a GPU: the reference's main (main.rs:36-98) on its bundled
+pair, in one process and as two / three ranks sharing the GPU (row bands over gloo: RCCL
+refuses several ranks on one device).  Expected output: the committed golden run of the
+red-black oracle (tests/golden/bundled_main.npz), which equals the sequential one."""
+import os
+import signal
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import PKG_DIR, load_package
+
+pytestmark = pytest.mark.gpu
+
+load_package()
+from stereo_vision_amd import pipeline  # noqa: E402
+
+
+def test_single_process(golden_dir):
+    gold = np.load(golden_dir + "/bundled_main.npz")
+    left, _ = pipeline.pgm_reader(golden_dir + "/left.pgm")
+    right, _ = pipeline.pgm_reader(golden_dir + "/right.pgm")
+    lines = []
+    labels, iters = pipeline.run(left, right, log=lines.append)
+    assert iters == int(gold["iters_cb"])
+    assert np.array_equal(labels.astype(np.int32), gold["labels_cb"])
+    assert np.array_equal(labels.astype(np.int32), gold["labels_seq"])
+    assert pipeline.check_disparity_map(labels)
+    assert any("Graph is consistent" in s for s in lines)
+    energy = float([s for s in lines if "energy" in s][-1].split()[-1])
+    assert abs(energy - float(gold["energy_cb"])) <= 1e-9 * abs(float(gold["energy_cb"]))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_the_gpu(tmp_path, golden_dir, world):
+    gold = np.load(golden_dir + "/bundled_main.npz")
+    out_pgm = tmp_path / "bands.pgm"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(PKG_DIR, "pipeline.py"), golden_dir + "/left.pgm", golden_dir + "/right.pgm",
+           str(out_pgm), "--backend", "gloo"]
+    # own session, so that a hang can be ended with the whole group (launcher + ranks)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path),
+                            start_new_session=True)
+    try:
+        stdout, stderr = proc.communicate(timeout=100)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        stdout, stderr = proc.communicate()
+        pytest.fail("ranks hung: " + stdout[-2000:] + stderr[-2000:])
+    assert proc.returncode == 0, stdout[-2000:] + stderr[-2000:]
+    assert "%d iterations of diffusion ended" % int(gold["iters_cb"]) in stdout
+    assert "Disparity map is consistent: true" in stdout
+    m, maxval = pipeline.pgm_reader(str(out_pgm))
+    assert maxval == 40
+    assert np.array_equal(m.astype(np.int32), gold["labels_cb"])
