@@ -84,6 +84,9 @@ int og_dedup_f64(const double *a, int n, double tol, double *out)
     return cur;
 }
 
+/* frees arrays handed out by og*_create_array_of_epsilons */
+void og_free(void *p) { free(p); }
+
 /* ---- cost volume ------------------------------------------------------- */
 
 /* q_t(d) = |L[i][j] - R[i][j-d]| (diffusion_graph.rs:71-76,120-121) materialised

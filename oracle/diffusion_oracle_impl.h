@@ -515,6 +515,79 @@ int FN(co_diffusion_while_not_consistent)(GRAPH *g, double epsilon, int batch_si
     return -1;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Epsilon search: diffusion_stereo/src/epsilon_search.rs                      */
+
+static int FN(cmp_double)(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* epsilon_search.rs:39-86.  Gaps of every vertex to its pixel's minimum and of every
+ * existing edge to its pixel pair's minimum, sorted ascending, then dedup_f64(tolerance).
+ * *out is malloc'ed (caller frees with free()); returns the count, or -1 where the
+ * reference's assert_ge! would fire (a gap below zero) or memory runs out. */
+long FN(create_array_of_epsilons)(const GRAPH *g, double tolerance, double **out)
+{
+    size_t cap = 1024, n = 0;
+    double *a = (double *)malloc(sizeof(double) * cap);
+    if (!a) return -1;
+#define PUSH(v)                                                           \
+    do {                                                                  \
+        if (n == cap) {                                                   \
+            cap *= 2;                                                     \
+            double *b_ = (double *)realloc(a, sizeof(double) * cap);      \
+            if (!b_) { free(a); return -1; }                              \
+            a = b_;                                                       \
+        }                                                                 \
+        a[n++] = (double)(v);                                             \
+    } while (0)
+    for (int i = 0; i < g->H; ++i)
+        for (int j = 0; j < g->W; ++j) {
+            REAL mv = FN(min_penalty_vertex)(g, i, j, NULL);
+            for (int d = 0; d < g->D; ++d) {
+                if (j < d) continue;
+                REAL v = FN(vertex_penalty_with_potentials)(g, i, j, d);
+                if (v < mv) { free(a); return -1; }
+                PUSH(v - mv);
+                for (int nb = 0; nb < 4; ++nb) {
+                    if (!og_neighbor_exists(i, j, nb, g->H, g->W)) continue;
+                    REAL me = FN(min_penalty_edge)(g, i, j, nb);
+                    for (int n_d = 0; n_d < g->D; ++n_d)
+                        if (FN(edge_exists)(g, i, j, nb, d, n_d)) {
+                            REAL e = FN(edge_penalty_with_potential)(g, i, j, nb, d, n_d);
+                            if (e < me) { free(a); return -1; }
+                            PUSH(e - me);
+                        }
+                }
+            }
+        }
+#undef PUSH
+    qsort(a, n, sizeof(double), FN(cmp_double));
+    double *u = (double *)malloc(sizeof(double) * (n ? n : 1));
+    if (!u) { free(a); return -1; }
+    int m = og_dedup_f64(a, (int)n, tolerance, u);
+    free(a);
+    *out = u;
+    return m;
+}
+
+/* epsilon_search.rs:94-112: binary search for the first array element whose
+ * epsilon-consistent sub-graph is non-empty.  Needs co_alloc'ed masks.  n >= 1. */
+double FN(epsilon_search)(GRAPH *g, const double *array, long n)
+{
+    long first = 0, last = n - 1, median = (first + last) / 2;
+    while (first < last) {
+        FN(co_initialize_with_epsilon)(g, array[median]);
+        FN(co_crossing_out)(g);
+        if (FN(co_is_not_empty)(g)) last = median;
+        else first = median + 1;
+        median = (first + last) / 2;
+    }
+    return array[median];
+}
+
 #undef POT
 #undef DUM
 #undef VERT

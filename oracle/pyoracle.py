@@ -96,6 +96,12 @@ def lib():
             f("co_find_best_labeling").argtypes = [P, P]
             f("co_diffusion_while_not_consistent").restype = I
             f("co_diffusion_while_not_consistent").argtypes = [P, C.c_double, I, I, I]
+            f("create_array_of_epsilons").restype = C.c_long
+            f("create_array_of_epsilons").argtypes = [P, C.c_double, C.POINTER(C.POINTER(C.c_double))]
+            f("epsilon_search").restype = C.c_double
+            f("epsilon_search").argtypes = [P, P, C.c_long]
+        L.og_free.argtypes = [P]
+        L.og_free.restype = None
         L.og_neighbor_exists.argtypes = [I] * 5
         L.og_neighbor_index.argtypes = [I, I, I] + [C.POINTER(C.c_int)] * 3
         L.og_number_of_neighbors.argtypes = [I] * 4
@@ -348,6 +354,21 @@ class OracleGraph:
     def diffusion_while_not_consistent(self, eps, batch_size, max_batches=1000, schedule=0):
         return self._f("co_diffusion_while_not_consistent")(self._g, eps, batch_size, max_batches,
                                                             schedule)
+
+    # -- epsilon_search.rs --
+    def create_array_of_epsilons(self, tolerance):
+        out = C.POINTER(C.c_double)()
+        n = self._f("create_array_of_epsilons")(self._g, tolerance, C.byref(out))
+        if n < 0:
+            raise AssertionError("a penalty lies below its minimum (assert_ge!)")
+        arr = np.array([out[k] for k in range(n)], dtype=np.float64)
+        lib().og_free(out)
+        return arr
+
+    def epsilon_search(self, array):
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        assert len(a) != 0
+        return self._f("epsilon_search")(self._g, _ptr(a), len(a))
 
 
 # ---- fast O(D) oracle -----------------------------------------------------

@@ -105,6 +105,14 @@ bool CrossingOutGraph::is_not_empty() const
     return vertices_exist() && (on_device_ || edges_exist());
 }
 
+bool CrossingOutGraph::consistent_with_epsilon(double epsilon)
+{
+    if (on_device_) return diffusion_graph.crossing_out_on_device(epsilon, vertices_);
+    initialize_with_epsilon(epsilon);
+    crossing_out();
+    return is_not_empty();
+}
+
 bool CrossingOutGraph::vertices_exist() const
 {
     for (std::size_t i = 0; i < H_; ++i)

@@ -40,6 +40,9 @@ public:
     void initialize_edges(double epsilon);          // :102-130
     void crossing_out();                            // :135-183
     bool is_not_empty() const;                      // :187-193
+    // initialize_with_epsilon + crossing_out + is_not_empty in one call, in either mode
+    // (the sequence epsilon_search.rs:100-102 and crossing_out_graph.rs:258-264 run)
+    bool consistent_with_epsilon(double epsilon);
     bool vertices_exist() const;                    // :196-211
     bool edges_exist() const;                       // :214-246
     // :254-275.  Returns the number of iterations run; throws std::runtime_error if

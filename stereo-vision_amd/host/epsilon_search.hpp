@@ -1,0 +1,22 @@
+// Epsilon search (diffusion_stereo/src/epsilon_search.rs:39-112): the smallest epsilon, out of
+// all penalty gaps in the graph, whose epsilon-consistent sub-graph is non-empty.
+//
+// The array of gaps has one entry per vertex and per existing edge (O(H*W*4*D^2) values), so
+// building it is for small images, as in the reference (which leaves the search disabled in
+// its main).  The search itself runs the crossing-out of the graph's mode: on the device for a
+// CrossingOutGraph in device mode, on the host masks otherwise.
+#pragma once
+#include <vector>
+
+#include "crossing_out_graph.hpp"
+
+namespace stereo {
+
+// :39-86.  Sorted ascending, then dedup_f64(tolerance).  Throws std::runtime_error where the
+// reference's assert_ge! fires (a penalty below its minimum).
+std::vector<double> create_array_of_epsilons(CrossingOutGraph &crossing_out_graph, double tolerance);
+
+// :94-112.  Binary search over `array` (non-empty, sorted ascending).
+double epsilon_search(CrossingOutGraph &crossing_out_graph, const std::vector<double> &array);
+
+}  // namespace stereo

@@ -6,6 +6,7 @@
 #include <limits>
 
 #include "crossing_out_graph.hpp"
+#include "epsilon_search.hpp"
 #include "diffusion_graph.hpp"
 
 using namespace stereo;
@@ -156,6 +157,38 @@ int main()
         CHECK(na == nb);
         CHECK(a.simple_best_labeling() == b.simple_best_labeling());
         CHECK(b.is_not_empty());
+    }
+    for (bool on_device : {false, true}) {   // diffusion_stereo/src/epsilon_search.rs:115-170
+        {   // :115-128 (test_epsilon_search_zero)
+            CrossingOutGraph c = CrossingOutGraph::initialize(
+                DiffusionGraph::initialize(Img{{0, 0}}, Img{{0, 0}}, 2, 1.), on_device);
+            const std::vector<double> array = create_array_of_epsilons(c, 0.01);
+            CHECK(epsilon_search(c, array) == 0.);
+        }
+        {   // :131-145 (test_epsilon_search)
+            CrossingOutGraph c = CrossingOutGraph::initialize(
+                DiffusionGraph::initialize(Img{{1, 1}}, Img{{1, 0}}, 2, 1.), on_device);
+            c.diffusion_graph.set_potential(0, 0, 2, 0, 9.4);
+            c.diffusion_graph.set_potential(0, 1, 0, 0, -1.8);
+            c.diffusion_graph.set_potential(0, 1, 0, 1, 6.7);
+            CHECK(epsilon_search(c, {0., 1., 2., 3., 4., 5., 6., 7., 8., 9.}) == 9.);
+        }
+        {   // :148-170 (test_create_array_of_epsilons)
+            CrossingOutGraph c = CrossingOutGraph::initialize(
+                DiffusionGraph::initialize(Img{{1, 1}}, Img{{1, 0}}, 2, 1.), on_device);
+            c.diffusion_graph.set_potential(0, 0, 2, 0, 0.6);
+            c.diffusion_graph.set_potential(0, 1, 0, 0, -0.3);
+            c.diffusion_graph.set_potential(0, 1, 0, 1, 0.1);
+            std::vector<double> array = create_array_of_epsilons(c, 0.);
+            CHECK(array.size() == 3 && array[0] == 0. && close(array[1], 1.4, 1e-6) && close(array[2], 1.4, 1e-6));
+            array = create_array_of_epsilons(c, 1.5);
+            CHECK(array.size() == 2 && array[0] == 0. && close(array[1], 1.4, 1e-6));
+        }
+    }
+    {   // utils.rs:250-268 (dedup_f64)
+        CHECK((dedup_f64({1., 1.5, 2., 3.}, 1.) == std::vector<double>{1., 3.}));
+        CHECK((dedup_f64({0.}, 0.) == std::vector<double>{0.}));
+        CHECK((dedup_f64({1., 1.5, 2., 3.}, 0.) == std::vector<double>{1., 1.5, 2., 3.}));
     }
     {   // diffusion_stereo/src/utils.rs:214-247
         CHECK(number_of_neighbors(0, 1, 2, 3) == 3 && number_of_neighbors(1, 1, 3, 3) == 4);

@@ -4,7 +4,8 @@
 //
 //   stereovision LEFT.pgm RIGHT.pgm OUT.pgm [--max-disparity N] [--smoothing X]
 //                [--epsilon E] [--batch B] [--max-batches M] [--dtype f64|f32]
-//                [--decode crossing|crossing-host|belief] [--iterations K]
+//                [--decode crossing|crossing-host|belief|epsilon-search] [--iterations K]
+//                [--tolerance T]
 //                [--schedule red-black|raster] [--quiet]
 //
 // --decode crossing (default) is the reference pipeline: diffusion batches on the GPU
@@ -12,6 +13,10 @@
 // the smallest surviving label per pixel.  --decode crossing-host keeps the reference's
 // vertex and edge masks on the host instead (O(H*W*D^2) bytes: small images only).
 // --decode belief runs --iterations diffusion iterations and takes the per-pixel argmin.
+// --decode epsilon-search (epsilon_search.rs, disabled in the reference's main) runs
+// --iterations iterations, collects all penalty gaps (small images only; merged within
+// --tolerance), binary-searches the smallest epsilon with a non-empty consistent sub-graph
+// and labels with it.
 // --schedule raster sweeps in the reference's sequential order (same results as its
 // CPU implementation up to rounding; one small launch per anti-diagonal, so slower).
 #include <cstdio>
@@ -22,6 +27,7 @@
 
 #include "crossing_out_graph.hpp"
 #include "diffusion_graph.hpp"
+#include "epsilon_search.hpp"
 #include "pgm.hpp"
 
 int main(int argc, char **argv)
@@ -33,9 +39,9 @@ int main(int argc, char **argv)
     }
     const std::string left_path = argv[1], right_path = argv[2], out_path = argv[3];
     std::size_t max_disparity = 40, batch = 200, max_batches = 1000, iterations = 200;
-    double smoothing = 1.2, epsilon = -1.;
+    double smoothing = 1.2, epsilon = -1., tolerance = 1e-9;
     int dtype = DS_F64;
-    bool crossing = true, host_masks = false, verbose = true, raster = false;
+    bool crossing = true, host_masks = false, verbose = true, raster = false, search = false;
     for (int a = 4; a < argc; ++a) {
         const std::string o = argv[a];
         auto need = [&](const char *name) -> const char * {
@@ -54,13 +60,15 @@ int main(int argc, char **argv)
         else if (o == "--dtype") dtype = std::strcmp(need("--dtype"), "f32") == 0 ? DS_F32 : DS_F64;
         else if (o == "--decode") {
             const std::string mode = need("--decode");
-            if (mode != "crossing" && mode != "crossing-host" && mode != "belief") {
+            if (mode != "crossing" && mode != "crossing-host" && mode != "belief" && mode != "epsilon-search") {
                 std::fprintf(stderr, "unknown --decode %s\n", mode.c_str());
                 return 2;
             }
             crossing = mode != "belief";
             host_masks = mode == "crossing-host";
+            search = mode == "epsilon-search";
         }
+        else if (o == "--tolerance") tolerance = std::strtod(need("--tolerance"), nullptr);
         else if (o == "--schedule") {
             const std::string mode = need("--schedule");
             if (mode != "raster" && mode != "red-black") {
@@ -85,7 +93,16 @@ int main(int argc, char **argv)
         DiffusionGraph graph = DiffusionGraph::initialize(left.matrix, right.matrix, max_disparity, smoothing, dtype);
         graph.raster_order = raster;
         Matrix disparity_map;
-        if (crossing) {
+        if (search) {
+            CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph), true);
+            cog.diffusion_graph.diffusion(1, iterations, verbose);
+            const std::vector<double> array = create_array_of_epsilons(cog, tolerance);
+            std::printf("Array size: %zu\n", array.size());
+            const double found = epsilon_search(cog, array);
+            std::printf("Smallest consistent epsilon: %.17g\n", found);
+            if (!cog.consistent_with_epsilon(found)) throw std::runtime_error("no epsilon in the array is consistent");
+            disparity_map = cog.simple_best_labeling();
+        } else if (crossing) {
             CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph), !host_masks);
             cog.diffusion_while_not_consistent(epsilon, batch, max_batches, verbose);
             std::printf("Finding disparity map ...\n");

@@ -50,6 +50,24 @@ inline std::size_t number_of_neighbors(std::size_t i, std::size_t j, std::size_t
 // utils.rs:109-114
 inline bool approx_equal(double x, double y, double epsilon) { return !(std::fabs(x - y) > epsilon); }
 
+// utils.rs:137-163: keeps the first element of every run of values within `tolerance` of
+// that first element -- and always the last element of the (sorted) array.
+inline std::vector<double> dedup_f64(const std::vector<double> &array, double tolerance)
+{
+    std::vector<double> unique_values;
+    if (array.empty()) return unique_values;
+    std::size_t i = 0, last_kept = 0;
+    while (i < array.size()) {
+        unique_values.push_back(array[i]);
+        last_kept = i;
+        std::size_t j = i + 1;
+        while (j < array.size() && approx_equal(array[i], array[j], tolerance)) ++j;
+        i = j;
+    }
+    if (last_kept != array.size() - 1) unique_values.push_back(array.back());
+    return unique_values;
+}
+
 // utils.rs:121-130
 inline bool check_disparity_map(const Matrix &disparity_map)
 {

@@ -59,6 +59,32 @@ def test_cli_raster_schedule_reproduces_sequential_run(tmp_path, golden_dir):
     assert abs(float(last_energy.split()[1]) - float(gold["energy_seq"])) <= 1e-9 * abs(float(gold["energy_seq"]))
 
 
+def test_cli_epsilon_search(tmp_path, golden_dir):
+    """--decode epsilon-search against the oracle's restatement of epsilon_search.rs on the
+    same phi (red-black oracle, 60 iterations on the bundled pair)."""
+    from oracle.pyoracle import OracleGraph
+    left, _, _ = pyoracle.pgm_reader(os.path.join(golden_dir, "left.pgm"))
+    right, _, _ = pyoracle.pgm_reader(os.path.join(golden_dir, "right.pgm"))
+    o = OracleGraph(left, right, 40, 1.2)
+    for _ in range(60):
+        o.diffusion_act_checkerboard()
+    o.co_alloc(True)
+    array = o.create_array_of_epsilons(1e-9)
+    want = o.epsilon_search(array)
+    o.initialize_with_epsilon(want)
+    o.crossing_out()
+    out_pgm = tmp_path / "eps.pgm"
+    run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
+                          os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--decode", "epsilon-search",
+                          "--iterations", "60", "--quiet"],
+                         capture_output=True, text=True, timeout=100, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stdout + run.stderr
+    found = float([ln for ln in run.stdout.splitlines() if ln.startswith("Smallest consistent epsilon")][0].split()[-1])
+    assert abs(found - want) <= 1e-9 * max(1.0, abs(want))
+    m, _, _ = pyoracle.pgm_reader(str(out_pgm))
+    assert np.array_equal(m.astype(np.int32), o.simple_best_labeling())
+
+
 def test_cli_belief_decode(tmp_path, golden_dir):
     gold = np.load(os.path.join(golden_dir, "bundled_seq_100.npz"))
     out_pgm = tmp_path / "belief.pgm"

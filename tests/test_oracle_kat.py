@@ -558,6 +558,44 @@ def test_pgm_reader_rejects_wrong_count(tmp_path):
         po.pgm_reader(str(p))
 
 
+# ------------------------------------------------------- epsilon_search.rs
+
+def test_epsilon_search_zero():
+    """diffusion_stereo/src/epsilon_search.rs:115-128"""
+    g = po.OracleGraph(np.zeros((1, 2), np.uint32), np.zeros((1, 2), np.uint32), 2, 1.0)
+    g.co_alloc(True)
+    array = g.create_array_of_epsilons(0.01)
+    assert g.epsilon_search(array) == 0.0
+
+
+def test_epsilon_search():
+    """epsilon_search.rs:131-145"""
+    g = po.OracleGraph([[1, 1]], [[1, 0]], 2, 1.0)
+    g.potentials[0][0][2][0] = 9.4
+    g.potentials[0][1][0][0] = -1.8
+    g.potentials[0][1][0][1] = 6.7
+    g.co_alloc(True)
+    assert g.epsilon_search([0., 1., 2., 3., 4., 5., 6., 7., 8., 9.]) == 9.0
+
+
+def test_create_array_of_epsilons():
+    """epsilon_search.rs:148-170"""
+    g = po.OracleGraph([[1, 1]], [[1, 0]], 2, 1.0)
+    g.potentials[0][0][2][0] = 0.6
+    g.potentials[0][1][0][0] = -0.3
+    g.potentials[0][1][0][1] = 0.1
+    g.co_alloc(True)
+    array = g.create_array_of_epsilons(0.0)
+    assert len(array) == 3
+    assert array[0] == 0.0
+    assert po.approx_equal(1.4, array[1], 1e-6)
+    assert po.approx_equal(1.4, array[2], 1e-6)
+    array = g.create_array_of_epsilons(1.5)
+    assert len(array) == 2
+    assert array[0] == 0.0
+    assert po.approx_equal(1.4, array[1], 1e-6)
+
+
 # ------------------------------------------------------------ f32 variant
 
 def test_f32_variant_agrees_on_a_kat():
