@@ -191,3 +191,71 @@ def test_placement_does_not_change_results(monkeypatch):
     assert np.array_equal(a.get_phi(0, 30), f.potentials[:30])
     a.close()
     b.close()
+
+
+def test_full_size_4k_256_properties(monkeypatch):
+    """The benchmark's own size (3840x2160, D=256, f32): properties that need no full-size
+    oracle -- non-decreasing dual energy, zero vertex residual, two half-image bands equal to
+    the whole image (checksum of checksums, energy, labels), the top rows bit-exact against
+    the O(D) oracle on a crop, crossing-out idempotent."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    H, W, D = 2160, 3840, 256
+    monkeypatch.setenv("DS_PLACEMENT_TRIES", "2")
+    left, right, _ = synth.synthetic_pair(H, W, D)
+    whole = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    cuts = [(0, 1080), (1080, 2160)]
+    bands = [diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32", row_begin=a, row_end=b) for a, b in cuts]
+    up, down = bands
+
+    def exchange(colour):
+        for src, dst in (((up, 1, 0), (down, 0, 1)), ((down, 0, 0), (up, 1, 1))):
+            sp, n = src[0].halo(colour, src[1], src[2])
+            dp, m = dst[0].halo(colour, dst[1], dst[2])
+            assert n == m
+            src[0].synchronize()
+            assert hip.hipMemcpy(C.c_void_p(dp), C.c_void_p(sp), C.c_size_t(n), 3) == 0
+
+    prev = whole.energy()
+    for _ in range(3):
+        for colour in (0, 1):
+            whole.sweep(colour)
+            for b in bands:
+                b.sweep(colour)
+            exchange(colour)
+        e, resid = whole.energy(with_residual=True)
+        assert e >= prev - 1e-6 * abs(prev) and resid <= 1e-3
+        prev = e
+    assert (up.checksum() + down.checksum()) % 2**64 == whole.checksum()
+    e_bands = up.energy() + down.energy()
+    assert abs(e_bands - prev) <= 1e-9 * abs(prev)
+    lab = whole.labels(0)
+    assert np.array_equal(np.concatenate([up.labels(0), down.labels(0)]), lab)
+    assert (lab <= np.minimum(np.arange(W)[None, :], D - 1)).all()
+    f = FastOracle(left[:40], right[:40], D, 1.2, dtype="f32")
+    f.iterate(3)
+    assert np.array_equal(whole.get_phi(0, 30), f.potentials[:30])
+    assert np.array_equal(lab[:30], f.labels(0)[:30])
+    for b in bands:
+        b.close()
+    r1 = whole.crossing_out(5.0)
+    r2 = whole.crossing_out(5.0)
+    assert np.array_equal(r1["labels"], r2["labels"]) and r1["not_empty"] == r2["not_empty"]
+    whole.close()
+
+
+def test_8k_wide_f64_band_bit_exact():
+    """The widest configuration's row width (7680, D=256, f64) on a 64-row image: bit-exact
+    against the O(D) oracle, and the raster-order sweep agrees with it on the dual optimum's
+    lower bound ordering (energy grows under both)."""
+    H, W, D = 64, 7680, 256
+    left, right, _ = synth.synthetic_pair(H, W, D)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f64")
+    f = FastOracle(left, right, D, 1.2, dtype="f64")
+    g.iterate(2)
+    f.iterate(2)
+    assert np.array_equal(g.get_phi(), f.potentials)
+    assert abs(g.energy() - f.energy()) <= 1e-9 * abs(f.energy())
+    assert np.array_equal(g.labels(0), f.labels(0))
+    assert g.checksum() == diffstereo.host_checksum(f.potentials, 0, H, W, D)
+    g.close()
