@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k_256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--band-of", type=int, default=1,
+                    help="with --gpus 1: time only band 0 of this many row bands, without halo exchange "
+                         "(what one GPU of a larger job sweeps; a timing, not a result)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +121,10 @@ def main():
     H, W, D, dtype, lam = wl["H"], wl["W"], wl["D"], wl["dtype"], 1.2
     left, right, _ = synth.synthetic_pair(H, W, D)
     rb, re = bands.partition_rows(H, world)[rank]
+    if args.band_of > 1:
+        if world != 1:
+            raise SystemExit("--band-of is a one-GPU measurement")
+        rb, re = bands.partition_rows(H, args.band_of)[0]
     graph = diffstereo.DiffusionGraph(left, right, D, lam, dtype=dtype, row_begin=rb, row_end=re,
                                       device=local_rank)
     engine = bands.HipBandEngine(graph, stage_through_host=rehearsal)
@@ -168,7 +175,7 @@ def main():
     energy = runner.energy()
 
     if rank == 0:
-        pl = valid_pairs(H, W, D)
+        pl = valid_pairs(H, W, D) if args.band_of == 1 else valid_pairs(re - rb, W, D)
         elem = 4 if dtype == "f32" else 8
         bytes_per_pl = 8 * elem + 1  # each phi row read once + written once, u8 cost read once
         my_pl = valid_pairs(re - rb, W, D)
@@ -189,7 +196,9 @@ def main():
             "config": {"workload": "synthetic %dx%d stereo pair, %d disparities, lambda=1.2, %s phi, "
                                    "u8 cost volume in HBM, red-black diffusion iterations" % (W, H, D, dtype),
                        "valid_pixel_labels": pl, "row_bands": world,
-                       "halo_exchange": transport},
+                       "halo_exchange": transport,
+                       **({"partial": "band 0 of %d (rows %d-%d) on one GPU, no halo exchange: timing only"
+                           % (args.band_of, rb, re)} if args.band_of > 1 else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_bytes / avg_launch_s / 1e9 if pmc_bytes and avg_launch_s > 0 else None,
