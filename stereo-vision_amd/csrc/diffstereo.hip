@@ -268,7 +268,9 @@ int place_phi(ds_handle *h)
     if (const char *v = std::getenv("DS_PLACEMENT_TRIES")) max_tries = std::atoi(v) > 0 ? std::atoi(v) : 1;
     const bool verbose = std::getenv("DS_PLACEMENT_VERBOSE") != nullptr;
     const bool exhaustive = mode && std::strcmp(mode, "exhaustive") == 0;
-    const size_t spacer_bytes = 16ull << 30;
+    // 32 GiB steps: three of them cross a 96 GiB region whatever the groups' size
+    size_t spacer_bytes = 32ull << 30;
+    if (const char *v = std::getenv("DS_PLACEMENT_SPACER_GIB")) spacer_bytes = (size_t)(std::atoi(v) > 0 ? std::atoi(v) : 32) << 30;
     std::vector<void *> spacers;
     auto cleanup = [&]() {
         for (void *p : spacers) (void)hipFree(p);
@@ -321,8 +323,9 @@ int place_phi(ds_handle *h)
             (void)hipFree(cand);
         }
         if (exhaustive) continue;
-        if (attempt > 0 && best <= 0.9 * worst) break;  // left the single-region state
-        if (since_gain >= 3) break;                     // nothing better within 48 GiB
+        if (attempt > 0 && best <= 0.92 * worst) break;  // left the single-region state
+        // nothing better although the candidates have moved across a whole region
+        if (since_gain >= 3 && spacers.size() * spacer_bytes >= (96ull << 30)) break;
     }
     cleanup();
     if (rc != DS_OK) return rc;

@@ -9,7 +9,7 @@ from __graft_entry__ import load_package  # noqa: E402
 load_package()
 from stereo_vision_amd import diffstereo, synth  # noqa: E402
 
-H, W, D = 2160, 3840, int(os.environ.get("D", "256"))
+H, W, D = int(os.environ.get("H", "2160")), int(os.environ.get("W", "3840")), int(os.environ.get("D", "256"))
 N = int(os.environ.get("ITERS", "8"))
 left, right, _ = synth.synthetic_pair(H, W, D)
 for rep in range(int(os.environ.get("REPS", "4"))):
