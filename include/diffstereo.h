@@ -86,7 +86,10 @@ int ds_get_cost(ds_handle *h, uint8_t *out);
  * (diffusion_graph.rs:264-341) under the red-black schedule: all pixels with
  * (i+j) even, then all with (i+j) odd.  Synchronous at return.  Only valid on a
  * handle that owns the whole image (bands need the halo exchange between colours:
- * use ds_sweep). */
+ * use ds_sweep).  For 128 < D <= 256 the iterations run in a kernel that keeps the first
+ * colour's potentials on chip (they are a function of the second colour's) and moves only
+ * the second colour's planes; the first colour's planes are brought up to date before the
+ * call returns.  Same bits as the half-sweeps; DS_FUSED=off at ds_create disables it. */
 int ds_iterate(ds_handle *h, int n_iters);
 
 /* The same n_iters calls of DiffusionGraph::diffusion_act, in the reference's own order:
@@ -168,6 +171,11 @@ int ds_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_
  * number of timed launches and their total / min / max duration in milliseconds. */
 int ds_profile_begin(ds_handle *h, int max_launches);
 int ds_profile_end(ds_handle *h, int *n_launches, double *total_ms, double *min_ms, double *max_ms);
+
+/* After ds_profile_end: the timed launches of that window split by kind -- half-sweeps
+ * (ds_sweep, and the one that completes ds_iterate) and whole-iteration launches of the fused
+ * kernel (ds_iterate on handles with 128 < D <= 256). */
+int ds_profile_split(ds_handle *h, int *n_half_sweeps, double *half_sweep_ms, int *n_fused, double *fused_ms);
 
 /* Geometry of the handle (any pointer may be NULL). */
 int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_begin, int *row_end);

@@ -12,6 +12,7 @@
 #include <new>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "kernels.hpp"
@@ -40,8 +41,15 @@ struct ds_handle {
     // phi: eight planes [colour][slot] of (Hb+2) x Wh x Dpad elements in two groups: group A
     // = slots 0,1 of both colours, group B = slots 2,3 of both colours.  The groups may be
     // separate allocations (see place_phi).  `phi` = base pointer of group A.
+    // Handles that can run whole iterations in one kernel (fused_waves > 0) hold a second set
+    // of colour-1 planes (`alt_off`, two more planes per group): the fused kernel reads the
+    // current colour-1 planes and writes the other set, then the two swap roles.
     void *phi = nullptr;
     void *phi_b = nullptr;        // group B when allocated apart, else NULL
+    int fused_waves = 0;          // wavefronts per block of the fused kernel; 0 = not available
+    int cu_count = 256;
+    long long alt_off[4] = {0, 0, 0, 0};
+    std::vector<int> prof_kind;   // per timed launch: 0 = half-sweep, 1 = fused iteration
     double placement_ms = 0.0;    // probe result of the chosen placement (0 = not probed)
     int placement_tries = 0;
     bool probing = false;         // launches belong to the placement probe
@@ -122,7 +130,11 @@ void set_planes(ds_handle *h, void *group_a, void *group_b)
     for (int colour = 0; colour < 2; ++colour)
         for (int slot = 0; slot < 4; ++slot)
             g.plane_off[colour][slot] = (slot / 2 ? b_off : 0) + (2 * colour + slot % 2) * h->plane_elems;
+    for (int slot = 0; slot < 4; ++slot)
+        h->alt_off[slot] = (slot / 2 ? b_off : 0) + (4 + slot % 2) * h->plane_elems;
 }
+
+int planes_per_group(const ds_handle *h) { return h->fused_waves ? 6 : 4; }
 
 int use_device(ds_handle *h)
 {
@@ -155,21 +167,25 @@ void release(ds_handle *h)
     delete h;
 }
 
-int launch_sweep(ds_handle *h, int colour, int row_begin, int row_end)
+int launch_sweep(ds_handle *h, int colour, int row_begin, int row_end, const ds::Geometry *planes = nullptr)
 {
     const int rows = row_end - row_begin;
     if (rows <= 0) return DS_OK;
+    const ds::Geometry &geo = planes ? *planes : h->g;
     const bool timed = h->prof && h->prof_n < h->prof_cap;
-    if (timed) HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
+        h->prof_kind[h->prof_n] = 0;
+    }
     const dim3 grid(h->grid_x, rows), block(ds::kBlock);
     int rc = dispatch(h, [&](auto t, auto lpp) -> int {
         using T = decltype(t);
         constexpr int L = decltype(lpp)::value;
         if (h->probing)
-            hipLaunchKernelGGL((ds::sweep_kernel<T, L, true>), grid, block, 0, h->stream, h->g,
+            hipLaunchKernelGGL((ds::sweep_kernel<T, L, true>), grid, block, 0, h->stream, geo,
                                static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels);
         else
-            hipLaunchKernelGGL((ds::sweep_kernel<T, L, false>), grid, block, 0, h->stream, h->g,
+            hipLaunchKernelGGL((ds::sweep_kernel<T, L, false>), grid, block, 0, h->stream, geo,
                                static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels);
         return DS_OK;
     });
@@ -180,6 +196,84 @@ int launch_sweep(ds_handle *h, int colour, int row_begin, int row_end)
         ++h->prof_n;
     }
     return DS_OK;
+}
+
+// One whole iteration over the colour-1 rows [row_begin, row_end) in one kernel: reads the
+// current colour-1 planes, writes the alternate set, and makes that set current.  The colour-0
+// planes are neither read nor written (see materialise_first_colour).
+// Rows of the second colour the fused kernel may update on this handle: it recomputes the
+// first colour's rows i-1, i, i+1, which read the second colour's rows i-2 .. i+2, and a band
+// holds only one halo row beyond its own.  So next to a neighbouring band the band's first /
+// last row is left to the half-sweeps; at the image's top / bottom there is nothing beyond.
+void fused_safe_rows(const ds_handle *h, int *begin, int *end)
+{
+    const ds::Geometry &g = h->g;
+    *begin = g.row0 == 0 ? 0 : g.row0 + 1;
+    *end = g.row0 + g.Hb == g.H ? g.H : g.row0 + g.Hb - 1;
+}
+
+int launch_fused(ds_handle *h, int row_begin, int row_end)
+{
+    const int rows = row_end - row_begin;
+    if (rows <= 0) return DS_OK;
+    ds::Geometry &g = h->g;
+    int safe_begin = 0, safe_end = 0;
+    fused_safe_rows(h, &safe_begin, &safe_end);
+    if (!h->fused_waves || row_begin < safe_begin || row_end > safe_end)
+        return fail(h, DS_ERR_ARG, "fused iteration outside the rows this handle can update in one kernel");
+    const bool timed = h->prof && h->prof_n < h->prof_cap;
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
+        h->prof_kind[h->prof_n] = 1;
+    }
+    const int fw = h->fused_waves, strip_cols = 2 * (fw - 1);
+    const int strips = (g.W + strip_cols - 1) / strip_cols;
+    // about two blocks per CU (a block fills a CU's LDS), whole segments of rows each
+    // Row segments of about 64 rows: measured at 4K x 256 f32 (ms per iteration, 4 / 8 / 16 / 32 /
+    // 48 segments of the 2160 rows): 8.25 / 7.85 / 7.17 / 6.77 / 6.76 -- many short blocks even
+    // out the slower border strips; the two extra red rows a segment recomputes cost 3 %.
+    int segs = (rows + 63) / 64;
+    (void)h->cu_count;
+    if (const char *e = std::getenv("DS_FUSED_SEGMENTS")) segs = std::atoi(e) > 0 ? std::atoi(e) : segs;  // tuning knob
+    if (segs > rows) segs = rows;
+    const int rows_per_seg = (rows + segs - 1) / segs;
+    const dim3 grid(strips, (rows + rows_per_seg - 1) / rows_per_seg), block(64 * fw);
+    ds::FusedPlanes np;
+    for (int s = 0; s < 4; ++s) np.out_off[s] = h->alt_off[s];
+    if (h->dtype == DS_F64) {
+        if (h->probing)
+            hipLaunchKernelGGL((ds::fused_iteration_kernel<double, 8, true>), grid, block, 0, h->stream, g,
+                               static_cast<double *>(h->phi), np, h->cost_px, h->lambda, row_begin, row_end, rows_per_seg);
+        else
+            hipLaunchKernelGGL((ds::fused_iteration_kernel<double, 8, false>), grid, block, 0, h->stream, g,
+                               static_cast<double *>(h->phi), np, h->cost_px, h->lambda, row_begin, row_end, rows_per_seg);
+    } else {
+        if (h->probing)
+            hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 16, true>), grid, block, 0, h->stream, g,
+                               static_cast<float *>(h->phi), np, h->cost_px, (float)h->lambda, row_begin, row_end,
+                               rows_per_seg);
+        else
+            hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 16, false>), grid, block, 0, h->stream, g,
+                               static_cast<float *>(h->phi), np, h->cost_px, (float)h->lambda, row_begin, row_end,
+                               rows_per_seg);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n + 1], h->stream));
+        ++h->prof_n;
+    }
+    for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
+    return DS_OK;
+}
+
+// After fused iterations the colour-0 planes are out of date: phi of colour 0 after iteration
+// n is F(phi of colour 1 after iteration n-1), and that input is what the alternate planes
+// hold right after a fused launch.
+int materialise_first_colour(ds_handle *h, int row_begin, int row_end)
+{
+    ds::Geometry before = h->g;
+    for (int s = 0; s < 4; ++s) before.plane_off[1][s] = h->alt_off[s];
+    return launch_sweep(h, 0, row_begin, row_end, &before);
 }
 
 int build_cost(ds_handle *h)
@@ -210,6 +304,17 @@ int init_phi(ds_handle *h)
         hipLaunchKernelGGL(ds::init_phi_kernel<float>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
                            h->stream, h->g, static_cast<float *>(h->phi));
     HIPCHK(h, hipGetLastError());
+    if (h->fused_waves) {  // the alternate colour-1 planes: same +inf / 0 pattern
+        ds::Geometry alt = h->g;
+        for (int s = 0; s < 4; ++s) alt.plane_off[1][s] = h->alt_off[s];
+        if (h->dtype == DS_F64)
+            hipLaunchKernelGGL(ds::init_phi_kernel<double>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
+                               h->stream, alt, static_cast<double *>(h->phi));
+        else
+            hipLaunchKernelGGL(ds::init_phi_kernel<float>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
+                               h->stream, alt, static_cast<float *>(h->phi));
+        HIPCHK(h, hipGetLastError());
+    }
     return DS_OK;
 }
 
@@ -223,14 +328,19 @@ int probe_sweeps(ds_handle *h, double *ms)
     } flag(h->probing);
     int rc = init_phi(h);
     const int r0 = h->g.row0, r1 = h->g.row0 + h->g.Hb;
-    for (int colour = 0; colour < 2 && rc == DS_OK; ++colour) rc = launch_sweep(h, colour, r0, r1);
+    // a handle that iterates with the fused kernel is placed for that kernel's streams
+    int f0 = 0, f1 = 0;
+    fused_safe_rows(h, &f0, &f1);
+    const bool fused = h->fused_waves > 0 && f1 - f0 >= (r1 - r0) / 2;
+    auto step = [&](int k) { return fused ? ((k & 1) ? DS_OK : launch_fused(h, f0, f1)) : launch_sweep(h, k & 1, r0, r1); };
+    for (int k = 0; k < 2 && rc == DS_OK; ++k) rc = step(k);
     if (rc != DS_OK) return rc;
     hipEvent_t a, b;
     HIPCHK(h, hipEventCreate(&a));
     HIPCHK(h, hipEventCreate(&b));
     HIPCHK(h, hipEventRecord(a, h->stream));
     const int reps = 2;
-    for (int k = 0; k < 2 * reps && rc == DS_OK; ++k) rc = launch_sweep(h, k & 1, r0, r1);
+    for (int k = 0; k < 2 * reps && rc == DS_OK; ++k) rc = step(k);
     hipError_t e = hipEventRecord(b, h->stream);
     if (e == hipSuccess) e = hipEventSynchronize(b);
     float t = 0;
@@ -253,7 +363,7 @@ int probe_sweeps(ds_handle *h, double *ms)
 // problems (a group under 1 GiB) and DS_PLACEMENT=off take one plain allocation.
 int place_phi(ds_handle *h)
 {
-    const size_t group_bytes = (size_t)(4 * h->plane_elems) * h->elem;
+    const size_t group_bytes = (size_t)(planes_per_group(h) * h->plane_elems) * h->elem;
     const char *mode = std::getenv("DS_PLACEMENT");
     const bool off = mode && std::strcmp(mode, "off") == 0;
     if (off || group_bytes < (1ull << 30)) {
@@ -378,6 +488,16 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     h->dtype = dtype;
     h->lambda = lambda;
     h->lpp = g.Dpad <= 64 ? 16 : g.Dpad <= 128 ? 32 : 64;
+    {
+        // The fused iteration kernel exists for one pixel per wavefront (128 < Dpad <= 256);
+        // its block holds 128 KiB of red rows in LDS: 16 wavefronts of f32, 8 of f64.
+        const char *e = std::getenv("DS_FUSED");
+        const bool off = e && std::strcmp(e, "off") == 0;
+        h->fused_waves = (h->lpp == 64 && !off) ? (dtype == DS_F64 ? 8 : 16) : 0;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0)
+            h->cu_count = cus;
+    }
     {
         const int ppw = 64 / h->lpp;
         const int per_round = (ds::kBlock / 64) * ppw;  // pixels one pass of the block's 4 waves covers
@@ -583,11 +703,22 @@ int ds_iterate(ds_handle *h, int n_iters)
         return fail(h, DS_ERR_STATE, "ds_iterate needs the whole image; a band must use ds_sweep + halo exchange");
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
-    for (int it = 0; it < n_iters; ++it)
-        for (int colour = 0; colour < 2; ++colour) {
-            rc = launch_sweep(h, colour, 0, h->g.H);
+    if (h->fused_waves && n_iters > 0) {
+        // n whole iterations that move only the second colour's planes, then the first
+        // colour's planes brought up to date: the same bits as 2n half-sweeps
+        for (int it = 0; it < n_iters; ++it) {
+            rc = launch_fused(h, 0, h->g.H);
             if (rc != DS_OK) return rc;
         }
+        rc = materialise_first_colour(h, 0, h->g.H);
+        if (rc != DS_OK) return rc;
+    } else {
+        for (int it = 0; it < n_iters; ++it)
+            for (int colour = 0; colour < 2; ++colour) {
+                rc = launch_sweep(h, colour, 0, h->g.H);
+                if (rc != DS_OK) return rc;
+            }
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DS_OK;
 }
@@ -745,6 +876,7 @@ int ds_profile_begin(ds_handle *h, int max_launches)
             h->events.push_back(e);
         }
         h->prof_cap = max_launches;
+        h->prof_kind.assign(max_launches, 0);
         h->prof_n = 0;
         h->prof = true;
         return DS_OK;
@@ -770,6 +902,28 @@ int ds_profile_end(ds_handle *h, int *n_launches, double *total_ms, double *min_
     if (total_ms) *total_ms = tot;
     if (min_ms) *min_ms = lo;
     if (max_ms) *max_ms = hi;
+    return DS_OK;
+}
+
+int ds_profile_split(ds_handle *h, int *n_half_sweeps, double *half_sweep_ms, int *n_fused, double *fused_ms)
+{
+    if (!h) return DS_ERR_ARG;
+    if (h->prof) return fail(h, DS_ERR_STATE, "ds_profile_split before ds_profile_end");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    int n[2] = {0, 0};
+    double t[2] = {0, 0};
+    for (int k = 0; k < h->prof_n; ++k) {
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->events[2 * k], h->events[2 * k + 1]));
+        const int kind = h->prof_kind[k] ? 1 : 0;
+        ++n[kind];
+        t[kind] += ms;
+    }
+    if (n_half_sweeps) *n_half_sweeps = n[0];
+    if (half_sweep_ms) *half_sweep_ms = t[0];
+    if (n_fused) *n_fused = n[1];
+    if (fused_ms) *fused_ms = t[1];
     return DS_OK;
 }
 

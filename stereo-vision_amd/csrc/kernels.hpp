@@ -582,6 +582,191 @@ __global__ __launch_bounds__(kBlock) void sweep_diagonal_kernel(Geometry g, T *_
     update_pixel<T, LPP>(g, phi, cost_c, colour, locate(g, i, j & 1, j >> 1, d0), lam, lambda, lseg, lane);
 }
 
+// ---- a whole iteration in one kernel: the first colour's potentials never reach memory ---
+// Under the red-black schedule phi of the colour-0 ("red") pixels is a pure function of the
+// colour-1 ("black") pixels' phi, and the black update reads nothing but the red result:
+//     phi_red = F(phi_black),   phi_black' = G(phi_red).
+// This kernel evaluates G(F(.)) for a strip of FC columns while marching down the rows,
+// keeping the red rows it needs in LDS: per (pixel pair, label) it reads 4 black rows and
+// writes 4, instead of reading 8 and writing 8 as the two half-sweeps do.  The black result
+// goes to a second set of colour-1 planes (np.out_off): blocks run in any order, so the
+// input must stay intact.  The arithmetic per pixel is the half-sweeps' own (same helpers,
+// same expression order), so the result is bit-identical to sweep_kernel(colour 0) followed
+// by sweep_kernel(colour 1).
+//
+// One wavefront = one pixel (LPP = 64: 128 < Dpad <= 256).  A strip row holds FR red and FR
+// black pixels; a black pixel at the strip's edge needs one red pixel outside it, so FW = FR + 1
+// wavefronts each produce one red pixel of row i+1, then (all but one) one black pixel of row
+// i.  Red pixel k of a row is at column c0 + 2k (even rows) or c0 - 1 + 2k (odd rows); black
+// pixel k at c0 + 2k + 1 or c0 + 2k; so black k has red k to its left, red k+1 to its right,
+// and red k + (row even ? 1 : 0) above and below it.
+//
+// LDS rings (rows of 256 labels): red row r's message up (slot 1) is used in the step that
+// makes it; its messages left / right (slots 0, 2) one step later; its message down (slot 3)
+// two steps later.  Two barriers per step separate producing row i+1 from consuming row i.
+template <typename T, int FW> struct FusedLds {
+    T slot1[FW][256];
+    T slot0[2][FW][256];
+    T slot2[2][FW][256];
+    T slot3[3][FW][256];
+};
+struct FusedPlanes {
+    long long out_off[4];  // element offsets (from the phi base) of the planes that receive phi_black'
+};
+
+// PROBE only changes the kernel's name (placement probes at ds_create, as for sweep_kernel).
+template <typename T, int FW, bool PROBE = false>
+__global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
+                                                                  const uint8_t *__restrict__ cost, T lambda,
+                                                                  int row_begin, int row_end, int rows_per_seg)
+{
+    using R = Real<T>;
+    constexpr int FR = FW - 1, FC = 2 * FR;
+    __shared__ FusedLds<T, FW> lds;
+    const T inf = R::inf();
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const int d0 = 4 * lane;
+    T lam[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
+    const int c0 = blockIdx.x * FC;
+    const int r0 = row_begin + blockIdx.y * rows_per_seg;
+    const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
+    // every pixel the block touches (halo reds included) has a left and a right neighbour and
+    // all D labels, and D fills the lanes: nothing to mask as long as the row is interior too
+    const bool cols_interior = g.D == 256 && c0 - 1 >= g.D && c0 + FC + 1 < g.W;
+    const uint8_t *cost_red = cost, *cost_black = cost + g.cost_colour_stride;
+
+    // A red pixel is made in two parts, so that its loads can be in flight while the wavefront
+    // computes the black pixel of the step before: fetch() issues the loads into registers,
+    // produce() computes from them and writes the four messages to LDS.
+    V4<T> pre_psi[4];
+    V4<T> pre_cost;
+    Pixel pre_px;
+    auto fetch = [&](int r) {
+        if (r < 0 || r >= g.H) return;
+        const int p = r & 1;
+        const int j = p == 0 ? c0 + 2 * k : c0 - 1 + 2 * k;
+        const int jc = j >> 1, il = r - g.row0 + 1;
+        if (cols_interior && r >= 1 && r + 1 < g.H) {
+            const long long own = (long long)il * g.row_stride + (long long)jc * g.Dpad + d0;
+            const long long nb[4] = {own + (long long)(p - 1) * g.Dpad, own - g.row_stride,
+                                     own + (long long)p * g.Dpad, own + g.row_stride};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) pre_psi[n] = ld4_nt(phi + g.plane_off[1][n ^ 2] + nb[n]);
+            pre_cost = unpack_cost<T>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                cost_red + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0)));
+        } else {
+            pre_px = locate(g, r, p, jc, d0);
+            pre_px.active = pre_px.active && j >= 0;
+            load_psi(g, phi, 1, pre_px, pre_psi);
+            pre_cost = load_cost<T>(cost_red, pre_px);
+        }
+    };
+    auto produce = [&](int r) {  // red pixel k of image row r: registers -> LDS
+        if (r < 0 || r >= g.H) return;
+        const int p = r & 1;
+        V4<T> psi[4], M[4], out[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) psi[n] = pre_psi[n];
+        const V4<T> qc = pre_cost;
+        messages_any<T, 64>(psi, lam, lambda, lane, lane, M);
+        if (cols_interior && r >= 1 && r + 1 < g.H) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const T avg = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * T(0.25);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) out[n].v[c] = avg - M[n].v[c];
+            }
+        } else {
+            const Pixel &px = pre_px;
+            const int K = px.j < g.D - 1 ? px.j : g.D - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                T acc = T(0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc += px.has[n] ? M[n].v[c] : T(0);
+                const T avg = divide_by_neighbours(qc.v[c] + acc, px.nn);
+                const bool valid = px.active && d0 + c <= K;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) out[n].v[c] = (valid && px.has[n]) ? avg - M[n].v[c] : inf;
+            }
+        }
+        store4(&lds.slot0[p][k][d0], out[0]);
+        store4(&lds.slot1[k][d0], out[1]);
+        store4(&lds.slot2[p][k][d0], out[2]);
+        store4(&lds.slot3[r % 3][k][d0], out[3]);
+    };
+    auto consume = [&](int i) {  // black pixel k (< FR) of image row i: LDS -> np planes
+        const int p = i & 1;
+        const int j = p == 0 ? c0 + 2 * k + 1 : c0 + 2 * k;
+        const int jc = j >> 1, il = i - g.row0 + 1;
+        const int kv = k + (p == 0 ? 1 : 0);
+        V4<T> psi[4], M[4];
+        if (cols_interior && i >= 1 && i + 1 < g.H) {
+            psi[0] = load4(&lds.slot2[p][k][d0]);
+            psi[1] = load4(&lds.slot3[(i + 2) % 3][kv][d0]);
+            psi[2] = load4(&lds.slot0[p][k + 1][d0]);
+            psi[3] = load4(&lds.slot1[kv][d0]);
+            const V4<T> qc = unpack_cost<T>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                cost_black + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0)));
+            messages_any<T, 64>(psi, lam, lambda, lane, lane, M);
+            const long long own = (long long)il * g.row_stride + (long long)jc * g.Dpad + d0;
+            V4<T> avg;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                avg.v[c] = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * T(0.25);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                V4<T> out;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out.v[c] = avg.v[c] - M[n].v[c];
+                st4_nt(phi + np.out_off[n] + own, out);
+            }
+        } else {
+            const Pixel px = locate(g, i, (i + 1) & 1, jc, d0);
+            const V4<T> none = splat(inf);
+            psi[0] = (px.active && px.has[0]) ? load4(&lds.slot2[p][k][d0]) : none;
+            psi[1] = (px.active && px.has[1]) ? load4(&lds.slot3[(i + 2) % 3][kv][d0]) : none;
+            psi[2] = (px.active && px.has[2]) ? load4(&lds.slot0[p][k + 1][d0]) : none;
+            psi[3] = (px.active && px.has[3]) ? load4(&lds.slot1[kv][d0]) : none;
+            const V4<T> qc = load_cost<T>(cost_black, px);
+            messages_any<T, 64>(psi, lam, lambda, lane, lane, M);
+            const int K = px.j < g.D - 1 ? px.j : g.D - 1;
+            V4<T> avg;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                T acc = T(0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc += px.has[n] ? M[n].v[c] : T(0);
+                avg.v[c] = divide_by_neighbours(qc.v[c] + acc, px.nn);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (px.active && px.has[n] && d0 <= K) {
+                    V4<T> out;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) out.v[c] = (d0 + c <= K) ? avg.v[c] - M[n].v[c] : inf;
+                    store4(phi + np.out_off[n] + px.own, out);
+                }
+            }
+        }
+    };
+
+    fetch(r0 - 1);
+    produce(r0 - 1);
+    fetch(r0);
+    produce(r0);
+    fetch(r0 + 1);
+    for (int i = r0; i < r1; ++i) {
+        produce(i + 1);
+        __syncthreads();
+        if (i + 1 < r1) fetch(i + 2);  // in flight while this step's black row is computed
+        if (k < FR) consume(i);
+        __syncthreads();
+    }
+}
+
 // ---- energy and residual ----------------------------------------------------------
 // Per pixel: min_d f_t(d) + sum over slots 2,3 of min_d( phi[t][n][d] + M_n(d) )
 // (diffusion_graph.rs:456-518; min_{d,d'} g evaluated as min_d of phi + M).  Each

@@ -45,6 +45,7 @@ SYMBOLS = {
     "ds_halo": (_I, [_P, _I, _I, _I, _PP, C.POINTER(C.c_size_t)]),
     "ds_profile_begin": (_I, [_P, _I]),
     "ds_profile_end": (_I, [_P, _IP, _DP, _DP, _DP]),
+    "ds_profile_split": (_I, [_P, _IP, _DP, _IP, _DP]),
     "ds_info": (_I, [_P, _IP, _IP, _IP, _IP, _IP, _IP]),
     "ds_placement_info": (_I, [_P, _IP, _DP, _IP]),
     "ds_checksum": (_I, [_P, C.POINTER(C.c_uint64)]),
@@ -221,6 +222,12 @@ class DiffusionGraph:
         n, tot, lo, hi = C.c_int(), C.c_double(), C.c_double(), C.c_double()
         self._chk(lib().ds_profile_end(self._h, C.byref(n), C.byref(tot), C.byref(lo), C.byref(hi)))
         return {"launches": n.value, "total_ms": tot.value, "min_ms": lo.value, "max_ms": hi.value}
+
+    def profile_split(self):
+        """After profile_end: launches and milliseconds by kind."""
+        n0, t0, n1, t1 = C.c_int(), C.c_double(), C.c_int(), C.c_double()
+        self._chk(lib().ds_profile_split(self._h, C.byref(n0), C.byref(t0), C.byref(n1), C.byref(t1)))
+        return {"half_sweeps": n0.value, "half_sweep_ms": t0.value, "fused": n1.value, "fused_ms": t1.value}
 
     def placement_info(self):
         n, ms, sp = C.c_int(), C.c_double(), C.c_int()

@@ -23,7 +23,10 @@ TOL = {"f64": 1e-9, "f32": 1e-5}
 # (H, W, D): odd sizes, W < D, D not a multiple of 4, every lanes-per-pixel variant
 SMALL = [(1, 1, 1), (1, 2, 2), (2, 1, 2), (1, 7, 3), (7, 1, 3), (2, 2, 2), (3, 3, 1), (5, 5, 40),
          (4, 7, 3), (6, 9, 5), (7, 12, 16), (5, 33, 40), (9, 8, 13), (3, 70, 64), (4, 37, 65),
-         (3, 50, 128), (2, 21, 129), (3, 40, 200), (2, 300, 256)]
+         (3, 50, 128), (2, 21, 129), (3, 40, 200), (2, 300, 256),
+         # one pixel per wavefront: whole iterations run in the fused kernel (strips of 30 / 14
+         # columns, row segments, interior fast path from column 256 on)
+         (20, 400, 256), (70, 330, 200), (5, 291, 256), (33, 61, 130), (1, 350, 256), (9, 31, 256)]
 
 
 @pytest.mark.parametrize("H,W,D", SMALL)
