@@ -92,6 +92,28 @@ int ds_get_cost(ds_handle *h, uint8_t *out);
  * call returns.  Same bits as the half-sweeps; DS_FUSED=off at ds_create disables it. */
 int ds_iterate(ds_handle *h, int n_iters);
 
+/* Whole iterations on a row band (128 < D <= 256; no counterpart in the reference, which has
+ * one process).  The fused kernel recomputes the first colour's rows i-1..i+1 for every row i
+ * of the second colour it updates, so next to a neighbouring band it must leave the band's
+ * first / last row to the half-sweeps.  One iteration of a band, all calls asynchronous on the
+ * handle's stream:
+ *   ds_sweep(h, 0, rows)        first colour, the band's two first and two last rows;
+ *   exchange ds_halo(0, ..)     as after any colour-0 half-sweep; wait for it;
+ *   ds_sweep_next(h, rows)      second colour, the band's first and last row, written to the
+ *                               planes the iteration is producing (not the current ones);
+ *   exchange ds_halo_next(..)   those two rows to the neighbours' ds_halo_next receive rows --
+ *                               this transfer runs while
+ *   ds_iterate_rows(h, b, e)    updates rows [b, e) = ds_fused_rows() in one kernel and makes
+ *                               the produced planes current.
+ * After the last iteration ds_finish_iterations brings the first colour's planes up to date
+ * (they are not written by ds_iterate_rows).  ds_fused_rows returns an empty range on handles
+ * without the kernel.  The result is bit-identical to half-sweeps with ds_sweep. */
+int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end);
+int ds_iterate_rows(ds_handle *h, int row_begin, int row_end);
+int ds_sweep_next(ds_handle *h, int row_begin, int row_end);
+int ds_halo_next(ds_handle *h, int side, int which, void **dev_ptr, size_t *bytes);
+int ds_finish_iterations(ds_handle *h);
+
 /* The same n_iters calls of DiffusionGraph::diffusion_act, in the reference's own order:
  * the raster loop of diffusion_graph.rs:264-269 (rows, then columns, vertex step + edge
  * step at each pixel).  A pixel reads its left and top neighbours after, and its right and

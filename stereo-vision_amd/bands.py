@@ -53,12 +53,12 @@ class HipBandEngine:
         self._views = {}
         graph.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    def _view(self, colour, side, which):
-        key = (colour, side, which)
-        if key not in self._views:
-            ptr, nbytes = self.g.halo(colour, side, which)
-            self._views[key] = torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
-        return self._views[key]
+    def _view(self, colour, side, which, upcoming=False):
+        # the library alternates between two sets of colour-1 planes: views are kept per pointer
+        ptr, nbytes = self.g.halo_next(side, which) if upcoming else self.g.halo(colour, side, which)
+        if ptr not in self._views:
+            self._views[ptr] = torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
+        return self._views[ptr]
 
     def sweep(self, colour, row_begin, row_end):
         if row_end > row_begin:
@@ -66,6 +66,28 @@ class HipBandEngine:
 
     def iterate(self, n_iters):
         self.g.iterate(n_iters)
+
+    # whole iterations in one kernel on a band (include/diffstereo.h, ds_iterate_rows)
+    def fused_rows(self):
+        return self.g.fused_rows()
+
+    def iterate_rows(self, row_begin, row_end):
+        self.g.iterate_rows(row_begin, row_end)
+
+    def sweep_next(self, row_begin, row_end):
+        if row_end > row_begin:
+            self.g.sweep_next(row_begin, row_end)
+
+    def finish_iterations(self):
+        self.g.finish_iterations()
+
+    def send_buffer_next(self, side):
+        v = self._view(1, side, 0, upcoming=True)
+        return v.cpu() if self.stage else v
+
+    def recv_buffer_next(self, side):
+        v = self._view(1, side, 1, upcoming=True)
+        return (torch.empty(v.shape, dtype=v.dtype), v) if self.stage else (v, v)
 
     def send_buffer(self, colour, side):
         v = self._view(colour, side, 0)
@@ -161,9 +183,62 @@ class BandRunner:
         if self.world == 1 and hasattr(self.e, "iterate"):
             self.e.iterate(n_iters)  # one band = the whole image: the library's own loop
             return
+        if n_iters > 0 and self._fused_band():
+            for _ in range(n_iters):
+                self._fused_iteration()
+            self.e.finish_iterations()
+            return
         for _ in range(n_iters):
             self.half_sweep(0)
             self.half_sweep(1)
+
+    def _fused_band(self):
+        """True if the engine can update the band's interior in one kernel per iteration and
+        the band is tall enough for that to be the bulk of it."""
+        if not hasattr(self.e, "fused_rows"):
+            return False
+        fb, fe = self.e.fused_rows()
+        return fe - fb >= 4 and self.e.row_end - self.e.row_begin >= 8
+
+    def _fused_iteration(self):
+        """One iteration of this band: the boundary rows with half-sweeps, everything else in
+        the kernel that keeps the first colour on chip.  Same result as two half_sweep()s.
+
+        The second colour's boundary rows are computed BEFORE the interior (they only need
+        the first colour's rows around them, which step 1 and the first exchange provide) and
+        go into the planes the iteration is producing, so that their exchange runs while the
+        interior kernel does."""
+        e = self.e
+        rb, re = e.row_begin, e.row_end
+        fb, fe = e.fused_rows()
+        if self.up is not None:
+            e.sweep(0, rb, rb + 2)
+        if self.down is not None:
+            e.sweep(0, re - 2, re)
+        reqs, recvs = self._post(0)
+        for r in reqs:
+            r.wait()
+        for side, buf in recvs:
+            e.commit_recv(0, side, buf)
+        if self.up is not None:
+            e.sweep_next(rb, rb + 1)
+        if self.down is not None:
+            e.sweep_next(re - 1, re)
+        ops, staged = [], []
+        for side, peer in ((0, self.up), (1, self.down)):
+            if peer is None:
+                continue
+            ops.append(dist.P2POp(dist.isend, e.send_buffer_next(side), peer, self.group))
+            buf, view = e.recv_buffer_next(side)
+            staged.append((buf, view))
+            ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        e.iterate_rows(fb, fe)  # the planes just written become the current ones
+        for r in reqs:
+            r.wait()
+        for buf, view in staged:
+            if buf is not view:
+                view.copy_(buf)
 
     def exchange_all(self):
         """Bring both colours' halos up to date (after set_phi on the bands)."""

@@ -229,11 +229,19 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
     const int fw = h->fused_waves, strip_cols = 2 * (fw - 1);
     const int strips = (g.W + strip_cols - 1) / strip_cols;
     // about two blocks per CU (a block fills a CU's LDS), whole segments of rows each
-    // Row segments of about 64 rows: measured at 4K x 256 f32 (ms per iteration, 4 / 8 / 16 / 32 /
-    // 48 segments of the 2160 rows): 8.25 / 7.85 / 7.17 / 6.77 / 6.76 -- many short blocks even
-    // out the slower border strips; the two extra red rows a segment recomputes cost 3 %.
+    // Row segments.  A block fills a CU's LDS, so the grid runs in rounds of at most cu_count
+    // blocks; many short blocks even out the slower border strips and whatever CUs a concurrent
+    // transfer kernel holds, and a segment only costs the two extra red rows it recomputes.
+    // Measured, 4K x 256 f32, ms per iteration for 4 / 8 / 16 / 32 / 48 segments of the 2160 rows:
+    // 8.25 / 7.85 / 7.17 / 6.77 / 6.76; a 270-row band next to RCCL traffic: 1.12 ms with 2..8
+    // segments, 1.07 with 12.  So: about 64 rows per segment, but at least 6 blocks per CU.
     int segs = (rows + 63) / 64;
-    (void)h->cu_count;
+    {
+        const int want = (6 * h->cu_count + strips - 1) / strips;
+        if (segs < want) segs = want;
+        if (segs > (rows + 15) / 16) segs = (rows + 15) / 16;
+        if (segs < 1) segs = 1;
+    }
     if (const char *e = std::getenv("DS_FUSED_SEGMENTS")) segs = std::atoi(e) > 0 ? std::atoi(e) : segs;  // tuning knob
     if (segs > rows) segs = rows;
     const int rows_per_seg = (rows + segs - 1) / segs;
@@ -695,6 +703,47 @@ int ds_sweep(ds_handle *h, int colour, int row_begin, int row_end)
     return launch_sweep(h, colour, row_begin, row_end);
 }
 
+int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end)
+{
+    if (!h || !row_begin || !row_end) return DS_ERR_ARG;
+    *row_begin = *row_end = h->g.row0;
+    if (h->fused_waves) fused_safe_rows(h, row_begin, row_end);
+    if (*row_end < *row_begin) *row_end = *row_begin;
+    return DS_OK;
+}
+
+int ds_iterate_rows(ds_handle *h, int row_begin, int row_end)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no fused iteration kernel (needs 128 < D <= 256)");
+    if (row_begin >= row_end) return fail(h, DS_ERR_ARG, "ds_iterate_rows needs at least one row");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    return launch_fused(h, row_begin, row_end);
+}
+
+int ds_sweep_next(ds_handle *h, int row_begin, int row_end)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no second set of colour-1 planes");
+    if (row_begin < h->g.row0 || row_end > h->g.row0 + h->g.Hb || row_begin > row_end)
+        return fail(h, DS_ERR_ARG, "rows outside the handle's band");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    ds::Geometry next = h->g;
+    for (int s = 0; s < 4; ++s) next.plane_off[1][s] = h->alt_off[s];
+    return launch_sweep(h, 1, row_begin, row_end, &next);
+}
+
+int ds_finish_iterations(ds_handle *h)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no fused iteration kernel");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    return materialise_first_colour(h, h->g.row0, h->g.row0 + h->g.Hb);
+}
+
 int ds_iterate(ds_handle *h, int n_iters)
 {
     if (!h) return DS_ERR_ARG;
@@ -858,6 +907,20 @@ int ds_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_
     const int slot = side == 0 ? (which == 0 ? 1 : 3) : (which == 0 ? 3 : 1);
     const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
     const long long off = g.plane_off[colour][slot] + (long long)il * g.row_stride;
+    *dev_ptr = static_cast<char *>(h->phi) + (size_t)off * h->elem;
+    *bytes = (size_t)g.Wh * g.Dpad * h->elem;
+    return DS_OK;
+}
+
+int ds_halo_next(ds_handle *h, int side, int which, void **dev_ptr, size_t *bytes)
+{
+    if (!h) return DS_ERR_ARG;
+    if ((side | 1) != 1 || (which | 1) != 1 || !dev_ptr || !bytes) return fail(h, DS_ERR_ARG, "bad ds_halo_next argument");
+    if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no second set of colour-1 planes");
+    const ds::Geometry &g = h->g;
+    const int slot = side == 0 ? (which == 0 ? 1 : 3) : (which == 0 ? 3 : 1);
+    const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
+    const long long off = h->alt_off[slot] + (long long)il * g.row_stride;
     *dev_ptr = static_cast<char *>(h->phi) + (size_t)off * h->elem;
     *bytes = (size_t)g.Wh * g.Dpad * h->elem;
     return DS_OK;

@@ -31,6 +31,11 @@ SYMBOLS = {
     "ds_iterate": (_I, [_P, _I]),
     "ds_iterate_raster": (_I, [_P, _I]),
     "ds_sweep": (_I, [_P, _I, _I, _I]),
+    "ds_fused_rows": (_I, [_P, _IP, _IP]),
+    "ds_iterate_rows": (_I, [_P, _I, _I]),
+    "ds_sweep_next": (_I, [_P, _I, _I]),
+    "ds_halo_next": (_I, [_P, _I, _I, _PP, C.POINTER(C.c_size_t)]),
+    "ds_finish_iterations": (_I, [_P]),
     "ds_energy": (_I, [_P, _DP, _DP]),
     "ds_labels": (_I, [_P, _I, _P]),
     "ds_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
@@ -145,6 +150,26 @@ class DiffusionGraph:
         self._chk(lib().ds_sweep(self._h, int(colour),
                                  self.row_begin if row_begin is None else int(row_begin),
                                  self.row_end if row_end is None else int(row_end)))
+
+    # whole iterations on a band (see include/diffstereo.h)
+    def fused_rows(self):
+        a, b = C.c_int(), C.c_int()
+        self._chk(lib().ds_fused_rows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def iterate_rows(self, row_begin, row_end):
+        self._chk(lib().ds_iterate_rows(self._h, int(row_begin), int(row_end)))
+
+    def sweep_next(self, row_begin, row_end):
+        self._chk(lib().ds_sweep_next(self._h, int(row_begin), int(row_end)))
+
+    def halo_next(self, side, which):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(lib().ds_halo_next(self._h, side, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def finish_iterations(self):
+        self._chk(lib().ds_finish_iterations(self._h))
 
     def energy(self, with_residual=False):
         e, r = C.c_double(), C.c_double()

@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, dtype, out):
+def _worker(rank, world, port, dtype, D, out):
     import torch
     import torch.distributed as dist
     load_package()
@@ -33,7 +33,7 @@ def _worker(rank, world, port, dtype, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        H, W, D, iters = 13, 45, 24, 3
+        H, W, iters = (13, 45, 3) if D <= 128 else (29, 75, 3)
         left, right = random_pair(H, W, seed=8)
         phi0 = random_phi(H, W, D, dtype, seed=2)
         rb, re = bands.partition_rows(H, world)[rank]
@@ -67,11 +67,13 @@ def _worker(rank, world, port, dtype, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dtype", [(2, "f32"), (3, "f64")])
-def test_two_ranks_one_gpu(world, dtype):
+@pytest.mark.parametrize("world,dtype,D", [(2, "f32", 24), (3, "f64", 24), (2, "f32", 256), (3, "f64", 140)])
+def test_two_ranks_one_gpu(world, dtype, D):
+    """D = 24: half-sweeps per colour.  D > 128: bands of 9-15 rows iterate with the fused
+    kernel in their interior (bands.BandRunner._fused_iteration)."""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), dtype, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), dtype, D, out), nprocs=world, join=True)
     for rank in range(world):
         assert out[rank] == (True, True), "rank %d: %s" % (rank, out[rank])
