@@ -230,6 +230,13 @@ def test_full_size_4k_256_properties(monkeypatch):
         assert e >= prev - 1e-6 * abs(prev) and resid <= 1e-3
         prev = e
     assert (up.checksum() + down.checksum()) % 2**64 == whole.checksum()
+    # the same three iterations through ds_iterate (whole iterations in the fused kernel)
+    fused = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    assert fused.fused_rows() == (0, H)
+    fused.iterate(3)
+    assert fused.checksum() == whole.checksum()
+    assert fused.energy() == prev
+    fused.close()
     e_bands = up.energy() + down.energy()
     assert abs(e_bands - prev) <= 1e-9 * abs(prev)
     lab = whole.labels(0)
