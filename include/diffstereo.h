@@ -86,14 +86,13 @@ int ds_get_cost(ds_handle *h, uint8_t *out);
  * (diffusion_graph.rs:264-341) under the red-black schedule: all pixels with
  * (i+j) even, then all with (i+j) odd.  Synchronous at return.  Only valid on a
  * handle that owns the whole image (bands need the halo exchange between colours:
- * use ds_sweep).  For 128 < D <= 256 the iterations run in a kernel that keeps the first
+ * use ds_sweep).  The iterations run in a kernel that keeps the first
  * colour's potentials on chip (they are a function of the second colour's) and moves only
  * the second colour's planes; the first colour's planes are brought up to date before the
  * call returns.  Same bits as the half-sweeps; DS_FUSED=off at ds_create disables it. */
 int ds_iterate(ds_handle *h, int n_iters);
 
-/* Whole iterations on a row band (128 < D <= 256; no counterpart in the reference, which has
- * one process).  The fused kernel recomputes the first colour's rows i-1..i+1 for every row i
+/* Whole iterations on a row band (no counterpart in the reference, which has one process).  The fused kernel recomputes the first colour's rows i-1..i+1 for every row i
  * of the second colour it updates, so next to a neighbouring band it must leave the band's
  * first / last row to the half-sweeps.  One iteration of a band, all calls asynchronous on the
  * handle's stream:
@@ -107,7 +106,7 @@ int ds_iterate(ds_handle *h, int n_iters);
  *                               the produced planes current.
  * After the last iteration ds_finish_iterations brings the first colour's planes up to date
  * (they are not written by ds_iterate_rows).  ds_fused_rows returns an empty range on handles
- * without the kernel.  The result is bit-identical to half-sweeps with ds_sweep. */
+ * created with DS_FUSED=off.  The result is bit-identical to half-sweeps with ds_sweep. */
 int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end);
 int ds_iterate_rows(ds_handle *h, int row_begin, int row_end);
 int ds_sweep_next(ds_handle *h, int row_begin, int row_end);
@@ -196,7 +195,7 @@ int ds_profile_end(ds_handle *h, int *n_launches, double *total_ms, double *min_
 
 /* After ds_profile_end: the timed launches of that window split by kind -- half-sweeps
  * (ds_sweep, and the one that completes ds_iterate) and whole-iteration launches of the fused
- * kernel (ds_iterate on handles with 128 < D <= 256). */
+ * kernel (ds_iterate, ds_iterate_rows). */
 int ds_profile_split(ds_handle *h, int *n_half_sweeps, double *half_sweep_ms, int *n_fused, double *fused_ms);
 
 /* Geometry of the handle (any pointer may be NULL). */

@@ -226,7 +226,7 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
         HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
         h->prof_kind[h->prof_n] = 1;
     }
-    const int fw = h->fused_waves, strip_cols = 2 * (fw - 1);
+    const int fw = h->fused_waves, strip_cols = 2 * (fw * (64 / h->lpp) - 1);
     const int strips = (g.W + strip_cols - 1) / strip_cols;
     // about two blocks per CU (a block fills a CU's LDS), whole segments of rows each
     // Row segments.  A block fills a CU's LDS, so the grid runs in rounds of at most cu_count
@@ -248,23 +248,19 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
     const dim3 grid(strips, (rows + rows_per_seg - 1) / rows_per_seg), block(64 * fw);
     ds::FusedPlanes np;
     for (int s = 0; s < 4; ++s) np.out_off[s] = h->alt_off[s];
-    if (h->dtype == DS_F64) {
+    int rc = dispatch(h, [&](auto t, auto lpp) -> int {
+        using T = decltype(t);
+        constexpr int L = decltype(lpp)::value;
+        constexpr int FW = sizeof(T) == 8 ? 8 : 16;
         if (h->probing)
-            hipLaunchKernelGGL((ds::fused_iteration_kernel<double, 8, true>), grid, block, 0, h->stream, g,
-                               static_cast<double *>(h->phi), np, h->cost_px, h->lambda, row_begin, row_end, rows_per_seg);
+            hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, true>), grid, block, 0, h->stream, g,
+                               static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end, rows_per_seg);
         else
-            hipLaunchKernelGGL((ds::fused_iteration_kernel<double, 8, false>), grid, block, 0, h->stream, g,
-                               static_cast<double *>(h->phi), np, h->cost_px, h->lambda, row_begin, row_end, rows_per_seg);
-    } else {
-        if (h->probing)
-            hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 16, true>), grid, block, 0, h->stream, g,
-                               static_cast<float *>(h->phi), np, h->cost_px, (float)h->lambda, row_begin, row_end,
-                               rows_per_seg);
-        else
-            hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 16, false>), grid, block, 0, h->stream, g,
-                               static_cast<float *>(h->phi), np, h->cost_px, (float)h->lambda, row_begin, row_end,
-                               rows_per_seg);
-    }
+            hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, false>), grid, block, 0, h->stream, g,
+                               static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end, rows_per_seg);
+        return DS_OK;
+    });
+    if (rc != DS_OK) return rc;
     HIPCHK(h, hipGetLastError());
     if (timed) {
         HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n + 1], h->stream));
@@ -497,11 +493,11 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     h->lambda = lambda;
     h->lpp = g.Dpad <= 64 ? 16 : g.Dpad <= 128 ? 32 : 64;
     {
-        // The fused iteration kernel exists for one pixel per wavefront (128 < Dpad <= 256);
-        // its block holds 128 KiB of red rows in LDS: 16 wavefronts of f32, 8 of f64.
+        // The fused iteration kernel's block holds 128 KiB of red rows in LDS: 16 wavefronts of
+        // f32, 8 of f64 (whatever the number of pixels per wavefront).
         const char *e = std::getenv("DS_FUSED");
         const bool off = e && std::strcmp(e, "off") == 0;
-        h->fused_waves = (h->lpp == 64 && !off) ? (dtype == DS_F64 ? 8 : 16) : 0;
+        h->fused_waves = off ? 0 : (dtype == DS_F64 ? 8 : 16);
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0)
             h->cu_count = cus;
@@ -715,7 +711,7 @@ int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end)
 int ds_iterate_rows(ds_handle *h, int row_begin, int row_end)
 {
     if (!h) return DS_ERR_ARG;
-    if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no fused iteration kernel (needs 128 < D <= 256)");
+    if (!h->fused_waves) return fail(h, DS_ERR_STATE, "the fused iteration kernel is switched off on this handle (DS_FUSED=off)");
     if (row_begin >= row_end) return fail(h, DS_ERR_ARG, "ds_iterate_rows needs at least one row");
     int rc = use_device(h);
     if (rc != DS_OK) return rc;

@@ -586,55 +586,60 @@ __global__ __launch_bounds__(kBlock) void sweep_diagonal_kernel(Geometry g, T *_
 // Under the red-black schedule phi of the colour-0 ("red") pixels is a pure function of the
 // colour-1 ("black") pixels' phi, and the black update reads nothing but the red result:
 //     phi_red = F(phi_black),   phi_black' = G(phi_red).
-// This kernel evaluates G(F(.)) for a strip of FC columns while marching down the rows,
-// keeping the red rows it needs in LDS: per (pixel pair, label) it reads 4 black rows and
-// writes 4, instead of reading 8 and writing 8 as the two half-sweeps do.  The black result
-// goes to a second set of colour-1 planes (np.out_off): blocks run in any order, so the
-// input must stay intact.  The arithmetic per pixel is the half-sweeps' own (same helpers,
-// same expression order), so the result is bit-identical to sweep_kernel(colour 0) followed
-// by sweep_kernel(colour 1).
+// This kernel evaluates G(F(.)) for a strip of columns while marching down the rows, keeping
+// the red rows it needs in LDS: per (pixel pair, label) it reads 4 black rows and writes 4,
+// instead of reading 8 and writing 8 as the two half-sweeps do.  The black result goes to a
+// second set of colour-1 planes (np.out_off): blocks run in any order, so the input must stay
+// intact.  The arithmetic per pixel is the half-sweeps' own (same helpers, same expression
+// order), so the result is bit-identical to sweep_kernel(colour 0) followed by
+// sweep_kernel(colour 1).
 //
-// One wavefront = one pixel (LPP = 64: 128 < Dpad <= 256).  A strip row holds FR red and FR
-// black pixels; a black pixel at the strip's edge needs one red pixel outside it, so FW = FR + 1
-// wavefronts each produce one red pixel of row i+1, then (all but one) one black pixel of row
-// i.  Red pixel k of a row is at column c0 + 2k (even rows) or c0 - 1 + 2k (odd rows); black
-// pixel k at c0 + 2k + 1 or c0 + 2k; so black k has red k to its left, red k+1 to its right,
-// and red k + (row even ? 1 : 0) above and below it.
+// A wavefront holds PPW = 64 / LPP pixels, a block FW wavefronts, i.e. NP = FW * PPW pixel
+// slots.  Each slot produces one red pixel of row i+1, then (all slots but the last) one black
+// pixel of row i: a strip row has FR = NP - 1 black pixels, FR red pixels inside the strip and
+// one red pixel outside it that an edge black pixel needs.  Red pixel kp of a row is at column
+// c0 + 2kp (even rows) or c0 - 1 + 2kp (odd rows); black pixel kp at c0 + 2kp + 1 or c0 + 2kp;
+// so black kp has red kp to its left, red kp+1 to its right, and red kp + (row even ? 1 : 0)
+// above and below it.
 //
-// LDS rings (rows of 256 labels): red row r's message up (slot 1) is used in the step that
-// makes it; its messages left / right (slots 0, 2) one step later; its message down (slot 3)
-// two steps later.  Two barriers per step separate producing row i+1 from consuming row i.
-template <typename T, int FW> struct FusedLds {
-    T slot1[FW][256];
-    T slot0[2][FW][256];
-    T slot2[2][FW][256];
-    T slot3[3][FW][256];
+// LDS rings (rows of DL = 4 * LPP labels): red row r's message up (slot 1) is used in the step
+// that makes it; its messages left / right (slots 0, 2) one step later; its message down (slot
+// 3) two steps later.  8 * NP * DL elements = 128 KiB for 16 wavefronts of f32 or 8 of f64.
+// Two barriers per step separate producing row i+1 from consuming row i.
+template <typename T, int NP, int DL> struct FusedLds {
+    T slot1[NP][DL];
+    T slot0[2][NP][DL];
+    T slot2[2][NP][DL];
+    T slot3[3][NP][DL];
 };
 struct FusedPlanes {
     long long out_off[4];  // element offsets (from the phi base) of the planes that receive phi_black'
 };
 
 // PROBE only changes the kernel's name (placement probes at ds_create, as for sweep_kernel).
-template <typename T, int FW, bool PROBE = false>
+template <typename T, int LPP, int FW, bool PROBE = false>
 __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
                                                                   const uint8_t *__restrict__ cost, T lambda,
                                                                   int row_begin, int row_end, int rows_per_seg)
 {
     using R = Real<T>;
-    constexpr int FR = FW - 1, FC = 2 * FR;
-    __shared__ FusedLds<T, FW> lds;
+    constexpr int PPW = 64 / LPP, NP = FW * PPW, FR = NP - 1, FC = 2 * FR, DL = 4 * LPP;
+    __shared__ FusedLds<T, NP, DL> lds;
     const T inf = R::inf();
-    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
-    const int d0 = 4 * lane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int kp = wave * PPW + q;  // the lane's pixel slot
     T lam[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
     const int c0 = blockIdx.x * FC;
     const int r0 = row_begin + blockIdx.y * rows_per_seg;
     const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
-    // every pixel the block touches (halo reds included) has a left and a right neighbour and
-    // all D labels, and D fills the lanes: nothing to mask as long as the row is interior too
-    const bool cols_interior = g.D == 256 && c0 - 1 >= g.D && c0 + FC + 1 < g.W;
+    // every pixel the block touches (the outside red included) has a left and a right neighbour
+    // and all D labels, and D fills the lanes: nothing to mask as long as the row is interior too
+    const bool cols_interior = g.D == DL && c0 - 1 >= g.D && c0 + FC + 1 < g.W;
+    // every pixel slot of this wavefront is a black pixel of the strip (false for the last one)
+    const bool wave_full = wave * PPW + PPW - 1 < FR;
     const uint8_t *cost_red = cost, *cost_black = cost + g.cost_colour_stride;
 
     // A red pixel is made in two parts, so that its loads can be in flight while the wavefront
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
     auto fetch = [&](int r) {
         if (r < 0 || r >= g.H) return;
         const int p = r & 1;
-        const int j = p == 0 ? c0 + 2 * k : c0 - 1 + 2 * k;
+        const int j = p == 0 ? c0 + 2 * kp : c0 - 1 + 2 * kp;
         const int jc = j >> 1, il = r - g.row0 + 1;
         if (cols_interior && r >= 1 && r + 1 < g.H) {
             const long long own = (long long)il * g.row_stride + (long long)jc * g.Dpad + d0;
@@ -663,14 +668,14 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
             pre_cost = load_cost<T>(cost_red, pre_px);
         }
     };
-    auto produce = [&](int r) {  // red pixel k of image row r: registers -> LDS
+    auto produce = [&](int r) {  // red pixel kp of image row r: registers -> LDS
         if (r < 0 || r >= g.H) return;
         const int p = r & 1;
         V4<T> psi[4], M[4], out[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) psi[n] = pre_psi[n];
         const V4<T> qc = pre_cost;
-        messages_any<T, 64>(psi, lam, lambda, lane, lane, M);
+        messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
         if (cols_interior && r >= 1 && r + 1 < g.H) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -692,25 +697,25 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
                 for (int n = 0; n < 4; ++n) out[n].v[c] = (valid && px.has[n]) ? avg - M[n].v[c] : inf;
             }
         }
-        store4(&lds.slot0[p][k][d0], out[0]);
-        store4(&lds.slot1[k][d0], out[1]);
-        store4(&lds.slot2[p][k][d0], out[2]);
-        store4(&lds.slot3[r % 3][k][d0], out[3]);
+        store4(&lds.slot0[p][kp][d0], out[0]);
+        store4(&lds.slot1[kp][d0], out[1]);
+        store4(&lds.slot2[p][kp][d0], out[2]);
+        store4(&lds.slot3[r % 3][kp][d0], out[3]);
     };
-    auto consume = [&](int i) {  // black pixel k (< FR) of image row i: LDS -> np planes
+    auto consume = [&](int i) {  // black pixel kp (< FR) of image row i: LDS -> np planes
         const int p = i & 1;
-        const int j = p == 0 ? c0 + 2 * k + 1 : c0 + 2 * k;
+        const int j = p == 0 ? c0 + 2 * kp + 1 : c0 + 2 * kp;
         const int jc = j >> 1, il = i - g.row0 + 1;
-        const int kv = k + (p == 0 ? 1 : 0);
+        const int kv = kp + (p == 0 ? 1 : 0);
         V4<T> psi[4], M[4];
-        if (cols_interior && i >= 1 && i + 1 < g.H) {
-            psi[0] = load4(&lds.slot2[p][k][d0]);
+        if (cols_interior && wave_full && i >= 1 && i + 1 < g.H) {
+            psi[0] = load4(&lds.slot2[p][kp][d0]);
             psi[1] = load4(&lds.slot3[(i + 2) % 3][kv][d0]);
-            psi[2] = load4(&lds.slot0[p][k + 1][d0]);
+            psi[2] = load4(&lds.slot0[p][kp + 1][d0]);
             psi[3] = load4(&lds.slot1[kv][d0]);
             const V4<T> qc = unpack_cost<T>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
                 cost_black + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0)));
-            messages_any<T, 64>(psi, lam, lambda, lane, lane, M);
+            messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
             const long long own = (long long)il * g.row_stride + (long long)jc * g.Dpad + d0;
             V4<T> avg;
 #pragma unroll
@@ -724,14 +729,15 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
                 st4_nt(phi + np.out_off[n] + own, out);
             }
         } else {
-            const Pixel px = locate(g, i, (i + 1) & 1, jc, d0);
+            Pixel px = locate(g, i, (i + 1) & 1, jc, d0);
+            px.active = px.active && kp < FR;  // the last pixel slot has no black pixel
             const V4<T> none = splat(inf);
-            psi[0] = (px.active && px.has[0]) ? load4(&lds.slot2[p][k][d0]) : none;
+            psi[0] = (px.active && px.has[0]) ? load4(&lds.slot2[p][kp][d0]) : none;
             psi[1] = (px.active && px.has[1]) ? load4(&lds.slot3[(i + 2) % 3][kv][d0]) : none;
-            psi[2] = (px.active && px.has[2]) ? load4(&lds.slot0[p][k + 1][d0]) : none;
+            psi[2] = (px.active && px.has[2]) ? load4(&lds.slot0[p][kp + 1][d0]) : none;
             psi[3] = (px.active && px.has[3]) ? load4(&lds.slot1[kv][d0]) : none;
             const V4<T> qc = load_cost<T>(cost_black, px);
-            messages_any<T, 64>(psi, lam, lambda, lane, lane, M);
+            messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
             const int K = px.j < g.D - 1 ? px.j : g.D - 1;
             V4<T> avg;
 #pragma unroll
@@ -762,7 +768,7 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
         produce(i + 1);
         __syncthreads();
         if (i + 1 < r1) fetch(i + 2);  // in flight while this step's black row is computed
-        if (k < FR) consume(i);
+        if (wave * PPW < FR) consume(i);
         __syncthreads();
     }
 }

@@ -69,8 +69,8 @@ def _worker(rank, world, port, dtype, D, out):
 
 @pytest.mark.parametrize("world,dtype,D", [(2, "f32", 24), (3, "f64", 24), (2, "f32", 256), (3, "f64", 140)])
 def test_two_ranks_one_gpu(world, dtype, D):
-    """D = 24: half-sweeps per colour.  D > 128: bands of 9-15 rows iterate with the fused
-    kernel in their interior (bands.BandRunner._fused_iteration)."""
+    """Bands of 4-7 rows (H = 13) fall back to half-sweeps per colour; bands of 9-15 rows
+    (H = 29) iterate with the fused kernel in their interior (bands.BandRunner._fused_iteration)."""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     out = mgr.dict()
