@@ -180,7 +180,8 @@ class BandRunner:
             e.commit_recv(colour, side, buf)
 
     def iterate(self, n_iters):
-        if self.world == 1 and hasattr(self.e, "iterate"):
+        if (self.world == 1 and hasattr(self.e, "iterate") and self.e.row_begin == 0
+                and self.e.row_end == self.e.H):
             self.e.iterate(n_iters)  # one band = the whole image: the library's own loop
             return
         if n_iters > 0 and self._fused_band():

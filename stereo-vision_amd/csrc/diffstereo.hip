@@ -251,13 +251,21 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
     int rc = dispatch(h, [&](auto t, auto lpp) -> int {
         using T = decltype(t);
         constexpr int L = decltype(lpp)::value;
-        constexpr int FW = sizeof(T) == 8 ? 8 : 16;
-        if (h->probing)
-            hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, true>), grid, block, 0, h->stream, g,
-                               static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end, rows_per_seg);
-        else
-            hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, false>), grid, block, 0, h->stream, g,
-                               static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end, rows_per_seg);
+        auto go = [&](auto fwc) {
+            constexpr int FW = decltype(fwc)::value;
+            if constexpr (sizeof(T) == 8 && FW == 16) return;  // 256 KiB of LDS: does not exist
+            else if (h->probing)
+                hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, true>), grid, block, 0, h->stream, g,
+                                   static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end,
+                                   rows_per_seg);
+            else
+                hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, false>), grid, block, 0, h->stream, g,
+                                   static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end,
+                                   rows_per_seg);
+        };
+        if (fw == 16) go(std::integral_constant<int, 16>{});
+        else if (fw == 8) go(std::integral_constant<int, 8>{});
+        else go(std::integral_constant<int, 4>{});
         return DS_OK;
     });
     if (rc != DS_OK) return rc;
@@ -394,7 +402,7 @@ int place_phi(ds_handle *h)
     if (e != hipSuccess)
         return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP,
                     std::string("hipMalloc(phi group A): ") + hipGetErrorString(e));
-    double best = 0.0, worst = 0.0;
+    double best = 0.0;
     int rc = DS_OK, since_gain = 0;
     for (int attempt = 0; attempt < max_tries; ++attempt) {
         if (attempt > 0) {  // push the next candidate further away
@@ -426,7 +434,6 @@ int place_phi(ds_handle *h)
             break;
         }
         ++h->placement_tries;
-        worst = ms > worst ? ms : worst;
         if (verbose) std::fprintf(stderr, "[diffstereo] placement try %d (%zu spacers): %.3f ms\n", attempt, spacers.size(), ms);
         since_gain = (!h->phi_b || ms < 0.98 * best) ? 0 : since_gain + 1;
         if (!h->phi_b || ms < best) {
@@ -437,8 +444,9 @@ int place_phi(ds_handle *h)
             (void)hipFree(cand);
         }
         if (exhaustive) continue;
-        if (attempt > 0 && best <= 0.92 * worst) break;  // left the single-region state
-        // nothing better although the candidates have moved across a whole region
+        // Stop when three more candidates, spread over a whole region, brought nothing.  (A first
+        // improvement is not the end: at 4K x 256 the fused kernel measured 7.47, 6.87, 6.37, 6.27,
+        // 6.29, 6.85, 6.87 ms per iteration for 0..6 spacers.)
         if (since_gain >= 3 && spacers.size() * spacer_bytes >= (96ull << 30)) break;
     }
     cleanup();
@@ -493,11 +501,16 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     h->lambda = lambda;
     h->lpp = g.Dpad <= 64 ? 16 : g.Dpad <= 128 ? 32 : 64;
     {
-        // The fused iteration kernel's block holds 128 KiB of red rows in LDS: 16 wavefronts of
-        // f32, 8 of f64 (whatever the number of pixels per wavefront).
+        // The fused iteration kernel's block: 8 wavefronts, whatever the number of pixels per
+        // wavefront.  f32: 64 KiB of LDS, two blocks per CU whose produce / consume phases
+        // interleave (4K x 256: 6.45 ms per iteration against 6.77 with one 16-wavefront block per
+        // CU and 6.90 with four 4-wavefront blocks, whose strips re-read more); f64: 128 KiB.
         const char *e = std::getenv("DS_FUSED");
         const bool off = e && std::strcmp(e, "off") == 0;
-        h->fused_waves = off ? 0 : (dtype == DS_F64 ? 8 : 16);
+        h->fused_waves = off ? 0 : 8;
+        if (const char *w = std::getenv("DS_FUSED_WAVES"))  // tuning knob: smaller blocks, several per CU
+            if (h->fused_waves && (std::atoi(w) == 4 || std::atoi(w) == 8 || (std::atoi(w) == 16 && dtype != DS_F64)))
+                h->fused_waves = std::atoi(w);
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0)
             h->cu_count = cus;
