@@ -161,7 +161,7 @@ def main():
 
     runner.iterate(args.warmup)
     fence()
-    launches_per_step = 2 if world == 1 else 6
+    launches_per_step = 2 if world == 1 else 8  # a band: boundary half-sweeps + the interior kernel
     graph.profile_begin(args.steps * launches_per_step + 4)
     t0 = time.perf_counter()
     runner.iterate(args.steps)
