@@ -228,13 +228,12 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
     }
     const int fw = h->fused_waves, strip_cols = 2 * (fw * (64 / h->lpp) - 1);
     const int strips = (g.W + strip_cols - 1) / strip_cols;
-    // about two blocks per CU (a block fills a CU's LDS), whole segments of rows each
-    // Row segments.  A block fills a CU's LDS, so the grid runs in rounds of at most cu_count
-    // blocks; many short blocks even out the slower border strips and whatever CUs a concurrent
-    // transfer kernel holds, and a segment only costs the two extra red rows it recomputes.
-    // Measured, 4K x 256 f32, ms per iteration for 4 / 8 / 16 / 32 / 48 segments of the 2160 rows:
-    // 8.25 / 7.85 / 7.17 / 6.77 / 6.76; a 270-row band next to RCCL traffic: 1.12 ms with 2..8
-    // segments, 1.07 with 12.  So: about 64 rows per segment, but at least 6 blocks per CU.
+    // Row segments.  One or two blocks fill a CU's LDS, so the grid runs in rounds; many short
+    // blocks even out the slower border strips and whatever CUs a concurrent transfer kernel
+    // holds, and a segment only costs the two extra red rows it recomputes.  Measured with
+    // 16-wavefront blocks, 4K x 256 f32, ms per iteration for 4 / 8 / 16 / 32 / 48 segments of the
+    // 2160 rows: 8.25 / 7.85 / 7.17 / 6.77 / 6.76; a 270-row band next to RCCL traffic: 1.12 ms with
+    // 2..8 segments, 1.07 with 12.  So: about 64 rows per segment, but at least 6 blocks per CU.
     int segs = (rows + 63) / 64;
     {
         const int want = (6 * h->cu_count + strips - 1) / strips;
