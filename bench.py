@@ -187,7 +187,7 @@ def main():
             # reported beside it, not mixed into the kernel's rate.
             bytes_per_pl = 4 * elem + 1
             kernel = "ds::fused_iteration_kernel<%s, %d, %d, false>" % (
-                tname, 16 if D <= 64 else 32 if D <= 128 else 64, 8)
+                tname, 16 if D <= 64 else 32 if D <= 128 else 64, 16 if dtype == "f32" else 8)
             kernel_s, launches = split["fused_ms"] / 1e3, split["fused"]
             units_per_launch = my_pl          # one launch = one iteration over the rank's pixels
         else:

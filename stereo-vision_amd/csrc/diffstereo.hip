@@ -252,8 +252,7 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
         constexpr int L = decltype(lpp)::value;
         auto go = [&](auto fwc) {
             constexpr int FW = decltype(fwc)::value;
-            if constexpr (sizeof(T) == 8 && FW == 16) return;  // 256 KiB of LDS: does not exist
-            else if (h->probing)
+            if (h->probing)
                 hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, true>), grid, block, 0, h->stream, g,
                                    static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end,
                                    rows_per_seg);
@@ -500,14 +499,14 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     h->lambda = lambda;
     h->lpp = g.Dpad <= 64 ? 16 : g.Dpad <= 128 ? 32 : 64;
     {
-        // The fused iteration kernel's block: 8 wavefronts, whatever the number of pixels per
-        // wavefront.  f32: 64 KiB of LDS, two blocks per CU whose produce / consume phases
-        // interleave (4K x 256: 6.45 ms per iteration against 6.77 with one 16-wavefront block per
-        // CU and 6.90 with four 4-wavefront blocks, whose strips re-read more); f64: 128 KiB.
+        // Wavefronts per block of the fused iteration kernel.  f32 (95 VGPRs): 16, measured at
+        // 4K x 256 6.24 ms per iteration against 6.42 with 8 (whose strips re-read 8/7 instead of
+        // 16/15 of phi); f64 (178 VGPRs, two wavefronts per SIMD): 8, 6.37 ms on a 540-row band of
+        // 8K x 256 against 6.80 with 4.
         const char *e = std::getenv("DS_FUSED");
         const bool off = e && std::strcmp(e, "off") == 0;
-        h->fused_waves = off ? 0 : 8;
-        if (const char *w = std::getenv("DS_FUSED_WAVES"))  // tuning knob: smaller blocks, several per CU
+        h->fused_waves = off ? 0 : (dtype == DS_F64 ? 8 : 16);
+        if (const char *w = std::getenv("DS_FUSED_WAVES"))  // tuning knob
             if (h->fused_waves && (std::atoi(w) == 4 || std::atoi(w) == 8 || (std::atoi(w) == 16 && dtype != DS_F64)))
                 h->fused_waves = std::atoi(w);
         int cus = 0;

@@ -586,72 +586,79 @@ __global__ __launch_bounds__(kBlock) void sweep_diagonal_kernel(Geometry g, T *_
 // Under the red-black schedule phi of the colour-0 ("red") pixels is a pure function of the
 // colour-1 ("black") pixels' phi, and the black update reads nothing but the red result:
 //     phi_red = F(phi_black),   phi_black' = G(phi_red).
-// This kernel evaluates G(F(.)) for a strip of columns while marching down the rows, keeping
-// the red rows it needs in LDS: per (pixel pair, label) it reads 4 black rows and writes 4,
-// instead of reading 8 and writing 8 as the two half-sweeps do.  The black result goes to a
-// second set of colour-1 planes (np.out_off): blocks run in any order, so the input must stay
-// intact.  The arithmetic per pixel is the half-sweeps' own (same helpers, same expression
-// order), so the result is bit-identical to sweep_kernel(colour 0) followed by
-// sweep_kernel(colour 1).
+// This kernel evaluates G(F(.)) for a strip of columns while marching down the rows: per
+// (pixel pair, label) it reads 4 black rows and writes 4, instead of reading 8 and writing 8
+// as the two half-sweeps do.  The black result goes to a second set of colour-1 planes
+// (np.out_off): blocks run in any order, so the input must stay intact.  The arithmetic per
+// pixel is the half-sweeps' own (same helpers, same expression order), so the result is
+// bit-identical to sweep_kernel(colour 0) followed by sweep_kernel(colour 1).
 //
-// A wavefront holds PPW = 64 / LPP pixels, a block FW wavefronts, i.e. NP = FW * PPW pixel
-// slots.  Each slot produces one red pixel of row i+1, then (all slots but the last) one black
-// pixel of row i: a strip row has FR = NP - 1 black pixels, FR red pixels inside the strip and
-// one red pixel outside it that an edge black pixel needs.  Red pixel kp of a row is at column
-// c0 + 2kp (even rows) or c0 - 1 + 2kp (odd rows); black pixel kp at c0 + 2kp + 1 or c0 + 2kp;
-// so black kp has red kp to its left, red kp+1 to its right, and red kp + (row even ? 1 : 0)
-// above and below it.
-//
-// LDS rings (rows of DL = 4 * LPP labels): red row r's message up (slot 1) is used in the step
-// that makes it; its messages left / right (slots 0, 2) one step later; its message down (slot
-// 3) two steps later.  8 * NP * DL elements = 128 KiB for 16 wavefronts of f32 or 8 of f64.
-// Two barriers per step separate producing row i+1 from consuming row i.
-template <typename T, int NP, int DL> struct FusedLds {
-    T slot1[NP][DL];
-    T slot0[2][NP][DL];
-    T slot2[2][NP][DL];
-    T slot3[3][NP][DL];
-};
+// A wavefront holds PPW = 64 / LPP pixel slots, a block FW wavefronts, i.e. NP = FW * PPW
+// slots.  Slot kp owns the column pair (a, a + 1), a = c0 - 1 + 2 kp (c0 even): in an odd row
+// its red pixel is at a and its black pixel at a + 1, in an even row the other way round.
+// Both vertical neighbours of the slot's black pixel are then the slot's own red pixels of
+// the rows above and below, and one horizontal neighbour is its own red pixel of the same
+// row: those three messages never leave the wavefront's registers.  Only the message a red
+// pixel sends to the neighbouring slot's black pixel goes through LDS (one row of labels per
+// slot, two deep), and one barrier per row step orders it.  NP slots produce NP red pixels
+// per row -- one of them outside the strip, for the black pixel at the strip's edge: NP /
+// (NP - 1) of the phi reads -- and NP - 1 black pixels.  Step i makes the red row i + 1 (its
+// loads were issued a step earlier), then the black row i.
 struct FusedPlanes {
     long long out_off[4];  // element offsets (from the phi base) of the planes that receive phi_black'
+};
+
+// component-wise select (a ?: on whole V4 objects would be done through memory)
+template <typename T> __device__ __forceinline__ V4<T> pick(bool c, const V4<T> &x, const V4<T> &y)
+{
+    V4<T> r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = c ? x.v[k] : y.v[k];
+    return r;
+}
+
+template <typename T, int NP, int DL> struct PairsLds {
+    T h[2][NP][DL];
 };
 
 // PROBE only changes the kernel's name (placement probes at ds_create, as for sweep_kernel).
 template <typename T, int LPP, int FW, bool PROBE = false>
 __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
-                                                                  const uint8_t *__restrict__ cost, T lambda,
-                                                                  int row_begin, int row_end, int rows_per_seg)
+                                                              const uint8_t *__restrict__ cost, T lambda,
+                                                              int row_begin, int row_end, int rows_per_seg)
 {
     using R = Real<T>;
-    constexpr int PPW = 64 / LPP, NP = FW * PPW, FR = NP - 1, FC = 2 * FR, DL = 4 * LPP;
-    __shared__ FusedLds<T, NP, DL> lds;
+    constexpr int PPW = 64 / LPP, NP = FW * PPW, NB = NP - 1, FC = 2 * NB, DL = 4 * LPP;
+    __shared__ PairsLds<T, NP, DL> lds;
     const T inf = R::inf();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
-    const int kp = wave * PPW + q;  // the lane's pixel slot
+    const int kp = wave * PPW + q;
     T lam[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
     const int c0 = blockIdx.x * FC;
+    const int a = c0 - 1 + 2 * kp;  // first column of the slot's pair (odd)
     const int r0 = row_begin + blockIdx.y * rows_per_seg;
     const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
-    // every pixel the block touches (the outside red included) has a left and a right neighbour
-    // and all D labels, and D fills the lanes: nothing to mask as long as the row is interior too
     const bool cols_interior = g.D == DL && c0 - 1 >= g.D && c0 + FC + 1 < g.W;
-    // every pixel slot of this wavefront is a black pixel of the strip (false for the last one)
-    const bool wave_full = wave * PPW + PPW - 1 < FR;
     const uint8_t *cost_red = cost, *cost_black = cost + g.cost_colour_stride;
 
-    // A red pixel is made in two parts, so that its loads can be in flight while the wavefront
-    // computes the black pixel of the step before: fetch() issues the loads into registers,
-    // produce() computes from them and writes the four messages to LDS.
+    // what fetch() keeps for produce(): the four neighbour rows and the packed cost word (the
+    // pixel's geometry is cheap to recompute and would cost a dozen registers to keep)
     V4<T> pre_psi[4];
-    V4<T> pre_cost;
-    Pixel pre_px;
-    auto fetch = [&](int r) {
+    uint32_t pre_cost = 0;
+    auto red_pixel = [&](int r) {
+        const int p = r & 1;
+        const int j = p ? a : a + 1;
+        Pixel px = locate(g, r, p, j >> 1, d0);
+        px.active = px.active && j >= 0;
+        return px;
+    };
+    auto fetch = [&](int r) {  // loads of the slot's red pixel of row r
         if (r < 0 || r >= g.H) return;
         const int p = r & 1;
-        const int j = p == 0 ? c0 + 2 * kp : c0 - 1 + 2 * kp;
+        const int j = p ? a : a + 1;
         const int jc = j >> 1, il = r - g.row0 + 1;
         if (cols_interior && r >= 1 && r + 1 < g.H) {
             const long long own = (long long)il * g.row_stride + (long long)jc * g.Dpad + d0;
@@ -659,22 +666,25 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
                                      own + (long long)p * g.Dpad, own + g.row_stride};
 #pragma unroll
             for (int n = 0; n < 4; ++n) pre_psi[n] = ld4_nt(phi + g.plane_off[1][n ^ 2] + nb[n]);
-            pre_cost = unpack_cost<T>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
-                cost_red + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0)));
+            pre_cost = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                cost_red + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0));
         } else {
-            pre_px = locate(g, r, p, jc, d0);
-            pre_px.active = pre_px.active && j >= 0;
-            load_psi(g, phi, 1, pre_px, pre_psi);
-            pre_cost = load_cost<T>(cost_red, pre_px);
+            const Pixel px = red_pixel(r);
+            load_psi(g, phi, 1, px, pre_psi);
+            pre_cost = (px.active && px.d0 <= px.j) ? *reinterpret_cast<const uint32_t *>(cost_red + px.cost) : 0u;
         }
     };
-    auto produce = [&](int r) {  // red pixel kp of image row r: registers -> LDS
+    // messages of the slot's red pixels, by the row that will use them
+    V4<T> down_prev = splat(inf), down_cur = splat(inf), side_cur = splat(inf);  // rows i-1, i, i
+    V4<T> down_next, side_next, up_next;                                         // row i+1
+    auto produce = [&](int r) {  // red pixel of row r: registers (+ one message to LDS)
+        down_next = side_next = up_next = splat(inf);
         if (r < 0 || r >= g.H) return;
         const int p = r & 1;
         V4<T> psi[4], M[4], out[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) psi[n] = pre_psi[n];
-        const V4<T> qc = pre_cost;
+        const V4<T> qc = unpack_cost<T>(pre_cost);
         messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
         if (cols_interior && r >= 1 && r + 1 < g.H) {
 #pragma unroll
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
                 for (int n = 0; n < 4; ++n) out[n].v[c] = avg - M[n].v[c];
             }
         } else {
-            const Pixel &px = pre_px;
+            const Pixel px = red_pixel(r);
             const int K = px.j < g.D - 1 ? px.j : g.D - 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -697,22 +707,27 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
                 for (int n = 0; n < 4; ++n) out[n].v[c] = (valid && px.has[n]) ? avg - M[n].v[c] : inf;
             }
         }
-        store4(&lds.slot0[p][kp][d0], out[0]);
-        store4(&lds.slot1[kp][d0], out[1]);
-        store4(&lds.slot2[p][kp][d0], out[2]);
-        store4(&lds.slot3[r % 3][kp][d0], out[3]);
+        // odd row: red at a, its right neighbour is the slot's own black pixel, its left one the
+        // previous slot's; even row: mirrored
+        store4(&lds.h[p][kp][d0], pick(p != 0, out[0], out[2]));
+        side_next = pick(p != 0, out[2], out[0]);
+        up_next = out[1];
+        down_next = out[3];
     };
-    auto consume = [&](int i) {  // black pixel kp (< FR) of image row i: LDS -> np planes
+    auto consume = [&](int i) {  // the slot's black pixel of row i
         const int p = i & 1;
-        const int j = p == 0 ? c0 + 2 * kp + 1 : c0 + 2 * kp;
+        const int j = p ? a + 1 : a;
+        const bool mine = p ? kp <= NB - 1 : kp >= 1;  // inside the strip
         const int jc = j >> 1, il = i - g.row0 + 1;
-        const int kv = kp + (p == 0 ? 1 : 0);
+        const int nbr = p ? kp + 1 : kp - 1;           // slot whose red pixel is the other horizontal neighbour
+        const bool wave_full = p ? (wave * PPW + PPW - 1 <= NB - 1) : (wave * PPW >= 1);
         V4<T> psi[4], M[4];
         if (cols_interior && wave_full && i >= 1 && i + 1 < g.H) {
-            psi[0] = load4(&lds.slot2[p][kp][d0]);
-            psi[1] = load4(&lds.slot3[(i + 2) % 3][kv][d0]);
-            psi[2] = load4(&lds.slot0[p][kp + 1][d0]);
-            psi[3] = load4(&lds.slot1[kv][d0]);
+            const V4<T> across = load4(&lds.h[p][nbr][d0]);
+            psi[0] = pick(p != 0, side_cur, across);
+            psi[1] = down_prev;
+            psi[2] = pick(p != 0, across, side_cur);
+            psi[3] = up_next;
             const V4<T> qc = unpack_cost<T>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
                 cost_black + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0)));
             messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
@@ -730,12 +745,17 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
             }
         } else {
             Pixel px = locate(g, i, (i + 1) & 1, jc, d0);
-            px.active = px.active && kp < FR;  // the last pixel slot has no black pixel
+            px.active = px.active && mine && j >= 0;
             const V4<T> none = splat(inf);
-            psi[0] = (px.active && px.has[0]) ? load4(&lds.slot2[p][kp][d0]) : none;
-            psi[1] = (px.active && px.has[1]) ? load4(&lds.slot3[(i + 2) % 3][kv][d0]) : none;
-            psi[2] = (px.active && px.has[2]) ? load4(&lds.slot0[p][kp + 1][d0]) : none;
-            psi[3] = (px.active && px.has[3]) ? load4(&lds.slot1[kv][d0]) : none;
+            const bool has_across = px.active && (p ? px.has[2] : px.has[0]);
+            const bool has_own = px.active && (p ? px.has[0] : px.has[2]);
+            V4<T> across = none;
+            if (has_across) across = load4(&lds.h[p][nbr][d0]);
+            const V4<T> own_side = pick(has_own, side_cur, none);
+            psi[0] = pick(p != 0, own_side, across);
+            psi[1] = pick(px.active && px.has[1], down_prev, none);
+            psi[2] = pick(p != 0, across, own_side);
+            psi[3] = pick(px.active && px.has[3], up_next, none);
             const V4<T> qc = load_cost<T>(cost_black, px);
             messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
             const int K = px.j < g.D - 1 ? px.j : g.D - 1;
@@ -758,17 +778,25 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
             }
         }
     };
+    auto rotate = [&]() {
+        down_prev = down_cur;
+        down_cur = down_next;
+        side_cur = side_next;
+    };
 
     fetch(r0 - 1);
     produce(r0 - 1);
+    rotate();
     fetch(r0);
     produce(r0);
+    rotate();
     fetch(r0 + 1);
+    __syncthreads();
     for (int i = r0; i < r1; ++i) {
-        produce(i + 1);
-        __syncthreads();
-        if (i + 1 < r1) fetch(i + 2);  // in flight while this step's black row is computed
-        if (wave * PPW < FR) consume(i);
+        produce(i + 1);                // writes this row parity's ring entry; the black row reads the other
+        if (i + 1 < r1) fetch(i + 2);  // in flight while the black row is computed
+        consume(i);
+        rotate();
         __syncthreads();
     }
 }

@@ -1,4 +1,5 @@
-// Feasibility probe: one whole iteration (red half-sweep + black half-sweep) in ONE kernel
+// Feasibility probe (kept as the record of the experiment that preceded the library's fused
+// kernel, and as a harness to time that kernel outside the library): one whole iteration (red half-sweep + black half-sweep) in ONE kernel
 // that never writes the red potentials to memory.  phi of the red pixels is a pure function
 // of the black pixels' phi, so a block marches down a strip of columns, keeps the red rows
 // it needs in LDS, and reads phi_black / writes phi_black' only: 34 instead of 66 bytes per
@@ -235,7 +236,7 @@ int main(int argc, char **argv)
             float ms = 0, best = 1e9f;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
+                hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 64, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
                                    dim3(64 * FW), 0, 0, g, phi, np, cost, lambda, 0, g.H, rps);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
