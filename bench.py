@@ -218,6 +218,13 @@ def main():
                          "traffic_bytes_per_launch": pmc_bytes,
                          "kernel": kernel,
                          "algorithmic_bytes_per_pixel_label": bytes_per_pl,
+                         "two_pass_bytes_per_pixel_label": 8 * elem + 1,
+                         "frac_at_two_pass_bytes": (8 * elem + 1) * units_per_launch * launches / kernel_s / 1e9
+                         / HBM_PEAK_GBS if kernel_s > 0 else 0.0,
+                         "note": ("one launch = one whole iteration that moves only the second colour's phi "
+                                  "(4*sizeof(T)+1 B per valid pixel*label); priced with the two half-sweeps' "
+                                  "8*sizeof(T)+1 B the same time reads frac_at_two_pass_bytes")
+                         if split["fused"] else "one launch = one colour's half-sweep",
                          "launches": launches,
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "other_launches": {"half_sweeps": split["half_sweeps"], "ms": split["half_sweep_ms"]}
