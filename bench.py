@@ -136,8 +136,8 @@ def main():
     elif world > 1:
         # Preflight: one halo exchange over RCCL.  If any rank cannot do it, every rank moves
         # the halos through pinned host memory over gloo instead (slower, and said so in
-        # the output line) rather than losing the run.
-        gloo = dist.new_group(backend="gloo")
+        # the output line) rather than losing the run.  The ranks agree through an RCCL
+        # all-reduce; the gloo group is only created if it is needed (it prints to stdout).
         ok = 1
         try:
             runner.exchange_all()
@@ -145,9 +145,10 @@ def main():
         except Exception as exc:  # noqa: BLE001
             ok = 0
             print("rank %d: RCCL halo exchange failed: %r" % (rank, exc), file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
+            gloo = dist.new_group(backend="gloo")
             engine = bands.HipBandEngine(graph, stage_through_host=True)
             runner = bands.BandRunner(engine, rank=rank, world=world, group=gloo)
             runner.exchange_all()
