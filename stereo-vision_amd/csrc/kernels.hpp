@@ -617,19 +617,19 @@ template <typename T> __device__ __forceinline__ V4<T> pick(bool c, const V4<T> 
     return r;
 }
 
-template <typename T, int NP, int DL> struct PairsLds {
+template <typename T, int NP, int DL> struct FusedLds {
     T h[2][NP][DL];
 };
 
 // PROBE only changes the kernel's name (placement probes at ds_create, as for sweep_kernel).
 template <typename T, int LPP, int FW, bool PROBE = false>
 __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
-                                                              const uint8_t *__restrict__ cost, T lambda,
-                                                              int row_begin, int row_end, int rows_per_seg)
+                                                                  const uint8_t *__restrict__ cost, T lambda,
+                                                                  int row_begin, int row_end, int rows_per_seg)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP, NP = FW * PPW, NB = NP - 1, FC = 2 * NB, DL = 4 * LPP;
-    __shared__ PairsLds<T, NP, DL> lds;
+    __shared__ FusedLds<T, NP, DL> lds;
     const T inf = R::inf();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
