@@ -269,3 +269,24 @@ def test_8k_wide_f64_band_bit_exact():
     assert np.array_equal(g.labels(0), f.labels(0))
     assert g.checksum() == diffstereo.host_checksum(f.potentials, 0, H, W, D)
     g.close()
+
+
+@pytest.mark.parametrize("waves,dtype,shape", [("8", "f32", (20, 400, 256)), ("4", "f32", (9, 150, 100)),
+                                               ("4", "f64", (12, 300, 256)), ("off", "f32", (20, 400, 256))])
+def test_fused_kernel_block_sizes_and_half_sweep_fallback(monkeypatch, waves, dtype, shape):
+    """The other block sizes of the fused iteration kernel (DS_FUSED_WAVES) and the half-sweep
+    path (DS_FUSED=off) give the same bits as the default."""
+    H, W, D = shape
+    if waves == "off":
+        monkeypatch.setenv("DS_FUSED", "off")
+    else:
+        monkeypatch.setenv("DS_FUSED_WAVES", waves)
+    left, right = random_pair(H, W, seed=H + W + D)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    assert (g.fused_rows() == (0, H)) == (waves != "off")
+    f = FastOracle(left, right, D, 1.2, dtype=dtype)
+    g.iterate(3)
+    f.iterate(3)
+    assert np.array_equal(g.get_phi(), f.potentials)
+    assert g.checksum() == diffstereo.host_checksum(f.potentials, 0, H, W, D)
+    g.close()
