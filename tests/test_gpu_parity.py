@@ -290,3 +290,28 @@ def test_fused_kernel_block_sizes_and_half_sweep_fallback(monkeypatch, waves, dt
     assert np.array_equal(g.get_phi(), f.potentials)
     assert g.checksum() == diffstereo.host_checksum(f.potentials, 0, H, W, D)
     g.close()
+
+
+def _random_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        D = int(rng.choice([rng.integers(1, 17), rng.integers(17, 65), rng.integers(65, 129), rng.integers(129, 257)]))
+        W = int(rng.choice([rng.integers(1, 12), rng.integers(12, 130), rng.integers(130, 420)]))
+        H = int(rng.integers(1, 36))
+        out.append((H, W, D, "f64" if rng.integers(0, 2) else "f32"))
+    return out
+
+
+@pytest.mark.parametrize("H,W,D,dtype", _random_shapes(48, seed=20240611))
+def test_random_shapes_bit_exact(H, W, D, dtype):
+    """Randomly drawn shapes (all pixel-per-wavefront variants, strips cut by the image edge,
+    single rows and columns, W < D): two iterations through ds_iterate against the O(D) oracle."""
+    left, right = random_pair(H, W, seed=H * 1000 + W)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    f = FastOracle(left, right, D, 1.2, dtype=dtype)
+    g.iterate(2)
+    f.iterate(2)
+    assert np.array_equal(g.get_phi(), f.potentials)
+    assert np.array_equal(g.labels(0), f.labels(0))
+    g.close()
