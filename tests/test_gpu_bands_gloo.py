@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, dtype, D, out):
+def _worker(rank, world, port, dtype, D, H, W, out):
     import torch
     import torch.distributed as dist
     load_package()
@@ -33,7 +33,7 @@ def _worker(rank, world, port, dtype, D, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        H, W, iters = (13, 45, 3) if D <= 128 else (29, 75, 3)
+        iters = 3
         left, right = random_pair(H, W, seed=8)
         phi0 = random_phi(H, W, D, dtype, seed=2)
         rb, re = bands.partition_rows(H, world)[rank]
@@ -67,13 +67,14 @@ def _worker(rank, world, port, dtype, D, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dtype,D", [(2, "f32", 24), (3, "f64", 24), (2, "f32", 256), (3, "f64", 140)])
-def test_two_ranks_one_gpu(world, dtype, D):
+@pytest.mark.parametrize("world,dtype,D,H,W", [(2, "f32", 24, 13, 45), (3, "f64", 24, 13, 45), (2, "f32", 256, 29, 75),
+                                               (3, "f64", 140, 29, 75), (2, "f64", 64, 17, 130), (3, "f32", 100, 40, 33)])
+def test_two_ranks_one_gpu(world, dtype, D, H, W):
     """Bands of 4-7 rows (H = 13) fall back to half-sweeps per colour; bands of 9-15 rows
     (H = 29) iterate with the fused kernel in their interior (bands.BandRunner._fused_iteration)."""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), dtype, D, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), dtype, D, H, W, out), nprocs=world, join=True)
     for rank in range(world):
         assert out[rank] == (True, True), "rank %d: %s" % (rank, out[rank])
