@@ -70,6 +70,11 @@ const char *ds_last_error(const ds_handle *h);
  * stream (NULL = the device's default stream).  Pending work is waited for first. */
 int ds_set_stream(ds_handle *h, void *hip_stream);
 
+/* The same without waiting for the stream that is being left: for callers that order the
+ * two streams themselves (events / stream waits), e.g. to run a band's boundary rows and
+ * their exchange beside the kernel that updates its interior. */
+int ds_switch_stream(ds_handle *h, void *hip_stream);
+
 /* Waits until all work queued by this handle has finished. */
 int ds_synchronize(ds_handle *h);
 
@@ -108,6 +113,9 @@ int ds_iterate(ds_handle *h, int n_iters);
  * (they are not written by ds_iterate_rows).  ds_fused_rows returns an empty range on handles
  * created with DS_FUSED=off.  The result is bit-identical to half-sweeps with ds_sweep. */
 int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end);
+/* ds_sweep (next = 0) or ds_sweep_next (next = 1, colour 1 only) over two disjoint row ranges in
+ * one launch: a band's first and last rows. */
+int ds_sweep_pair(ds_handle *h, int colour, int next, int row_begin, int row_end, int row_begin2, int row_end2);
 int ds_iterate_rows(ds_handle *h, int row_begin, int row_end);
 int ds_sweep_next(ds_handle *h, int row_begin, int row_end);
 int ds_halo_next(ds_handle *h, int side, int which, void **dev_ptr, size_t *bytes);

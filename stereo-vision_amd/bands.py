@@ -17,6 +17,8 @@ each pixel sees exactly the same operands.
 `BandRunner` is engine-agnostic: the engine supplies the sweep and the halo buffers.
 `HipBandEngine` is the product engine (C ABI of include/diffstereo.h).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -51,7 +53,42 @@ class HipBandEngine:
         self.H = graph.H
         self.stage = stage_through_host  # gloo rehearsal: halos travel via pinned host copies
         self._views = {}
-        graph.set_stream(torch.cuda.current_stream().cuda_stream)
+        # A main stream of its own, not the device's default stream: work queued on the default
+        # stream waits for every other stream, which would serialise the side stream with it.
+        self.main = torch.cuda.Stream()
+        self.main.wait_stream(torch.cuda.current_stream())
+        # boundary rows + exchanges beside the interior kernel.  Normal priority on purpose: with a
+        # high-priority stream in the chain main -> side -> RCCL's stream -> side -> main the
+        # device never drained (seen with RCCL send/recv on one MI355X), and the chain is queued
+        # before the interior kernel anyway, so its first launch does not wait behind it.
+        self.side = torch.cuda.Stream()
+        graph.set_stream(self.main.cuda_stream)
+
+    def beside(self):
+        """Context: library launches and torch work go to the side stream, which first waits for
+        everything queued on the main stream so far.  join() makes the main stream wait for it."""
+        engine = self
+
+        class _Beside:
+            def __enter__(self):
+                engine.side.wait_stream(engine.main)
+                self._ctx = torch.cuda.stream(engine.side)
+                self._ctx.__enter__()
+                engine.g.switch_stream(engine.side.cuda_stream)
+
+            def __exit__(self, *exc):
+                engine.g.switch_stream(engine.main.cuda_stream)
+                return self._ctx.__exit__(*exc)
+
+        return _Beside()
+
+    def join(self):
+        self.main.wait_stream(self.side)
+
+    def on_main(self):
+        """Context for everything BandRunner queues: torch's current stream = the engine's main
+        stream, so that the communication library orders itself against the library's launches."""
+        return torch.cuda.stream(self.main)
 
     def _view(self, colour, side, which, upcoming=False):
         # the library alternates between two sets of colour-1 planes: views are kept per pointer
@@ -77,6 +114,9 @@ class HipBandEngine:
     def sweep_next(self, row_begin, row_end):
         if row_end > row_begin:
             self.g.sweep_next(row_begin, row_end)
+
+    def sweep_pair(self, colour, upcoming, rows1, rows2):
+        self.g.sweep_pair(colour, upcoming, rows1, rows2)
 
     def finish_iterations(self):
         self.g.finish_iterations()
@@ -135,7 +175,7 @@ class HipBandEngine:
         return self.g.co_finish(empty, with_mask)
 
     def synchronize(self):
-        torch.cuda.current_stream().synchronize()
+        self.main.synchronize()
 
 
 class BandRunner:
@@ -161,7 +201,14 @@ class BandRunner:
             ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
         return (dist.batch_isend_irecv(ops) if ops else []), recvs
 
+    def _on_main(self):
+        return self.e.on_main() if hasattr(self.e, "on_main") else contextlib.nullcontext()
+
     def half_sweep(self, colour):
+        with self._on_main():
+            self._half_sweep(colour)
+
+    def _half_sweep(self, colour):
         e = self.e
         rb, re = e.row_begin, e.row_end
         if self.world == 1:
@@ -180,6 +227,10 @@ class BandRunner:
             e.commit_recv(colour, side, buf)
 
     def iterate(self, n_iters):
+        with self._on_main():
+            self._iterate(n_iters)
+
+    def _iterate(self, n_iters):
         if (self.world == 1 and hasattr(self.e, "iterate") and self.e.row_begin == 0
                 and self.e.row_end == self.e.H):
             self.e.iterate(n_iters)  # one band = the whole image: the library's own loop
@@ -190,8 +241,8 @@ class BandRunner:
             self.e.finish_iterations()
             return
         for _ in range(n_iters):
-            self.half_sweep(0)
-            self.half_sweep(1)
+            self._half_sweep(0)
+            self._half_sweep(1)
 
     def _fused_band(self):
         """True if the engine can update the band's interior in one kernel per iteration and
@@ -205,52 +256,66 @@ class BandRunner:
         """One iteration of this band: the boundary rows with half-sweeps, everything else in
         the kernel that keeps the first colour on chip.  Same result as two half_sweep()s.
 
-        The second colour's boundary rows are computed BEFORE the interior (they only need
-        the first colour's rows around them, which step 1 and the first exchange provide) and
-        go into the planes the iteration is producing, so that their exchange runs while the
-        interior kernel does."""
+        The boundary chain (first colour's two first / two last rows -> their exchange -> second
+        colour's first / last row, written into the planes the iteration is producing -> their
+        exchange) and the interior kernel both read only the planes of the previous iteration
+        and write disjoint rows, so engines that have a side stream run the chain there, beside
+        the interior kernel; the main stream waits for it before the next iteration."""
         e = self.e
         rb, re = e.row_begin, e.row_end
         fb, fe = e.fused_rows()
-        if self.up is not None:
-            e.sweep(0, rb, rb + 2)
-        if self.down is not None:
-            e.sweep(0, re - 2, re)
-        reqs, recvs = self._post(0)
-        for r in reqs:
-            r.wait()
-        for side, buf in recvs:
-            e.commit_recv(0, side, buf)
-        if self.up is not None:
-            e.sweep_next(rb, rb + 1)
-        if self.down is not None:
-            e.sweep_next(re - 1, re)
-        ops, staged = [], []
-        for side, peer in ((0, self.up), (1, self.down)):
-            if peer is None:
-                continue
-            ops.append(dist.P2POp(dist.isend, e.send_buffer_next(side), peer, self.group))
-            buf, view = e.recv_buffer_next(side)
-            staged.append((buf, view))
-            ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
-        reqs = dist.batch_isend_irecv(ops) if ops else []
+        both = self.up is not None and self.down is not None and hasattr(e, "sweep_pair")
+        beside = e.beside() if hasattr(e, "beside") else contextlib.nullcontext()
+        with beside:
+            if both:
+                e.sweep_pair(0, False, (rb, rb + 2), (re - 2, re))  # one launch for the four rows
+            else:
+                if self.up is not None:
+                    e.sweep(0, rb, rb + 2)
+                if self.down is not None:
+                    e.sweep(0, re - 2, re)
+            reqs, recvs = self._post(0)
+            for r in reqs:
+                r.wait()
+            for side, buf in recvs:
+                e.commit_recv(0, side, buf)
+            if both:
+                e.sweep_pair(1, True, (rb, rb + 1), (re - 1, re))
+            else:
+                if self.up is not None:
+                    e.sweep_next(rb, rb + 1)
+                if self.down is not None:
+                    e.sweep_next(re - 1, re)
+            ops, staged = [], []
+            for side, peer in ((0, self.up), (1, self.down)):
+                if peer is None:
+                    continue
+                ops.append(dist.P2POp(dist.isend, e.send_buffer_next(side), peer, self.group))
+                buf, view = e.recv_buffer_next(side)
+                staged.append((buf, view))
+                ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            for r in reqs:
+                r.wait()
+            for buf, view in staged:
+                if buf is not view:
+                    view.copy_(buf)
+        # main stream: does not wait for any of the above
         e.iterate_rows(fb, fe)  # the planes just written become the current ones
-        for r in reqs:
-            r.wait()
-        for buf, view in staged:
-            if buf is not view:
-                view.copy_(buf)
+        if hasattr(e, "join"):
+            e.join()
 
     def exchange_all(self):
         """Bring both colours' halos up to date (after set_phi on the bands)."""
         if self.world == 1:
             return
-        for colour in (0, 1):
-            reqs, recvs = self._post(colour)
-            for r in reqs:
-                r.wait()
-            for side, buf in recvs:
-                self.e.commit_recv(colour, side, buf)
+        with self._on_main():
+            for colour in (0, 1):
+                reqs, recvs = self._post(colour)
+                for r in reqs:
+                    r.wait()
+                for side, buf in recvs:
+                    self.e.commit_recv(colour, side, buf)
 
     def _reduce_flags(self, values, op):
         t = torch.tensor([int(v) for v in values], dtype=torch.int32)
@@ -265,19 +330,20 @@ class BandRunner:
             return
         e = self.e
         e.synchronize()
-        ops, recvs = [], []
-        for colour in (0, 1):
-            for side, peer in ((0, self.up), (1, self.down)):
-                if peer is None:
-                    continue
-                ops.append(dist.P2POp(dist.isend, e.co_send_buffer(colour, side), peer, self.group))
-                rb = e.co_recv_buffer(colour, side)
-                recvs.append((colour, side, rb))
-                ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
-        for r in (dist.batch_isend_irecv(ops) if ops else []):
-            r.wait()
-        for colour, side, buf in recvs:
-            e.co_commit_recv(colour, side, buf)
+        with self._on_main():
+            ops, recvs = [], []
+            for colour in (0, 1):
+                for side, peer in ((0, self.up), (1, self.down)):
+                    if peer is None:
+                        continue
+                    ops.append(dist.P2POp(dist.isend, e.co_send_buffer(colour, side), peer, self.group))
+                    rb = e.co_recv_buffer(colour, side)
+                    recvs.append((colour, side, rb))
+                    ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
+            for r in (dist.batch_isend_irecv(ops) if ops else []):
+                r.wait()
+            for colour, side, buf in recvs:
+                e.co_commit_recv(colour, side, buf)
 
     def crossing_out(self, epsilon, max_passes=1 << 30, with_mask=False):
         """CrossingOutGraph::initialize_with_epsilon + crossing_out + simple_best_labeling

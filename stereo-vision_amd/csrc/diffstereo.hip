@@ -167,9 +167,13 @@ void release(ds_handle *h)
     delete h;
 }
 
-int launch_sweep(ds_handle *h, int colour, int row_begin, int row_end, const ds::Geometry *planes = nullptr)
+// Half-sweep of `colour` over image rows [row_begin, row_end) and, in the same launch,
+// [row_begin2, row_end2) (may be empty).
+int launch_sweep(ds_handle *h, int colour, int row_begin, int row_end, const ds::Geometry *planes = nullptr,
+                 int row_begin2 = 0, int row_end2 = 0)
 {
-    const int rows = row_end - row_begin;
+    const int split = row_end - row_begin > 0 ? row_end - row_begin : 0;
+    const int rows = split + (row_end2 - row_begin2 > 0 ? row_end2 - row_begin2 : 0);
     if (rows <= 0) return DS_OK;
     const ds::Geometry &geo = planes ? *planes : h->g;
     const bool timed = h->prof && h->prof_n < h->prof_cap;
@@ -183,10 +187,12 @@ int launch_sweep(ds_handle *h, int colour, int row_begin, int row_end, const ds:
         constexpr int L = decltype(lpp)::value;
         if (h->probing)
             hipLaunchKernelGGL((ds::sweep_kernel<T, L, true>), grid, block, 0, h->stream, geo,
-                               static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels);
+                               static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels,
+                               split, row_begin2);
         else
             hipLaunchKernelGGL((ds::sweep_kernel<T, L, false>), grid, block, 0, h->stream, geo,
-                               static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels);
+                               static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, colour, row_begin, h->seg_pixels,
+                               split, row_begin2);
         return DS_OK;
     });
     if (rc != DS_OK) return rc;
@@ -667,6 +673,13 @@ int ds_set_stream(ds_handle *h, void *hip_stream)
     return DS_OK;
 }
 
+int ds_switch_stream(ds_handle *h, void *hip_stream)
+{
+    if (!h) return DS_ERR_ARG;
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    return DS_OK;
+}
+
 int ds_synchronize(ds_handle *h)
 {
     if (!h) return DS_ERR_ARG;
@@ -708,6 +721,24 @@ int ds_sweep(ds_handle *h, int colour, int row_begin, int row_end)
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
     return launch_sweep(h, colour, row_begin, row_end);
+}
+
+int ds_sweep_pair(ds_handle *h, int colour, int next, int row_begin, int row_end, int row_begin2, int row_end2)
+{
+    if (!h) return DS_ERR_ARG;
+    if (colour != 0 && colour != 1) return fail(h, DS_ERR_ARG, "colour must be 0 or 1");
+    if (next && (colour != 1 || !h->fused_waves))
+        return fail(h, DS_ERR_ARG, "only the second colour has upcoming planes (and not with DS_FUSED=off)");
+    const int lo = h->g.row0, hi = h->g.row0 + h->g.Hb;
+    if (row_begin < lo || row_end > hi || row_begin > row_end || row_begin2 < lo || row_end2 > hi ||
+        row_begin2 > row_end2 || (row_begin2 < row_end && row_begin < row_end2 && row_begin < row_end && row_begin2 < row_end2))
+        return fail(h, DS_ERR_ARG, "row ranges must lie inside the handle's band and not overlap");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    if (!next) return launch_sweep(h, colour, row_begin, row_end, nullptr, row_begin2, row_end2);
+    ds::Geometry upcoming = h->g;
+    for (int s = 0; s < 4; ++s) upcoming.plane_off[1][s] = h->alt_off[s];
+    return launch_sweep(h, 1, row_begin, row_end, &upcoming, row_begin2, row_end2);
 }
 
 int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end)

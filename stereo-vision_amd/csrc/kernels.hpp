@@ -500,13 +500,16 @@ __device__ __forceinline__ void update_pixel(const Geometry &g, T *phi, const ui
 template <typename T, int LPP, bool PROBE = false>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(Geometry g, T *__restrict__ phi,
                                                        const uint8_t *__restrict__ cost, T lambda,
-                                                       int colour, int row_begin, int seg_pixels)
+                                                       int colour, int row_begin, int seg_pixels,
+                                                       int split, int row_begin2)
 {
     constexpr int PPW = 64 / LPP;
     constexpr int WAVES = kBlock / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
-    const int i = row_begin + blockIdx.y;
+    // grid rows [0, split) are image rows from row_begin on, the rest image rows from row_begin2
+    // on (a band's first and last rows in one launch)
+    const int i = (int)blockIdx.y < split ? row_begin + blockIdx.y : row_begin2 + (blockIdx.y - split);
     const int s = (i + colour) & 1;
     T lam[4];
 #pragma unroll

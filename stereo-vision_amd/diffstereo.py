@@ -25,6 +25,7 @@ SYMBOLS = {
     "ds_destroy": (None, [_P]),
     "ds_last_error": (C.c_char_p, [_P]),
     "ds_set_stream": (_I, [_P, _P]),
+    "ds_switch_stream": (_I, [_P, _P]),
     "ds_synchronize": (_I, [_P]),
     "ds_build_cost": (_I, [_P]),
     "ds_get_cost": (_I, [_P, _P]),
@@ -32,6 +33,7 @@ SYMBOLS = {
     "ds_iterate_raster": (_I, [_P, _I]),
     "ds_sweep": (_I, [_P, _I, _I, _I]),
     "ds_fused_rows": (_I, [_P, _IP, _IP]),
+    "ds_sweep_pair": (_I, [_P, _I, _I, _I, _I, _I, _I]),
     "ds_iterate_rows": (_I, [_P, _I, _I]),
     "ds_sweep_next": (_I, [_P, _I, _I]),
     "ds_halo_next": (_I, [_P, _I, _I, _PP, C.POINTER(C.c_size_t)]),
@@ -127,6 +129,10 @@ class DiffusionGraph:
     def set_stream(self, hip_stream):
         self._chk(lib().ds_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def switch_stream(self, hip_stream):
+        """set_stream without waiting for the stream being left (the caller orders them)."""
+        self._chk(lib().ds_switch_stream(self._h, C.c_void_p(hip_stream)))
+
     def synchronize(self):
         self._chk(lib().ds_synchronize(self._h))
 
@@ -162,6 +168,10 @@ class DiffusionGraph:
 
     def sweep_next(self, row_begin, row_end):
         self._chk(lib().ds_sweep_next(self._h, int(row_begin), int(row_end)))
+
+    def sweep_pair(self, colour, upcoming, rows1, rows2):
+        self._chk(lib().ds_sweep_pair(self._h, int(colour), int(bool(upcoming)), int(rows1[0]), int(rows1[1]),
+                                      int(rows2[0]), int(rows2[1])))
 
     def halo_next(self, side, which):
         p, n = C.c_void_p(), C.c_size_t()

@@ -256,8 +256,8 @@ int main(int argc, char **argv)
     const int seg_pixels = 4;
     const dim3 grid(g.Wh / seg_pixels, g.H), block(ds::kBlock);
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((ds::sweep_kernel<float, 64, false>), grid, block, 0, 0, g, phi, cost, lambda, 0, 0, seg_pixels);
-    hipLaunchKernelGGL((ds::sweep_kernel<float, 64, false>), grid, block, 0, 0, g, phi, cost, lambda, 1, 0, seg_pixels);
+    hipLaunchKernelGGL((ds::sweep_kernel<float, 64, false>), grid, block, 0, 0, g, phi, cost, lambda, 0, 0, seg_pixels, g.H, 0);
+    hipLaunchKernelGGL((ds::sweep_kernel<float, 64, false>), grid, block, 0, 0, g, phi, cost, lambda, 1, 0, seg_pixels, g.H, 0);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipGetLastError());
