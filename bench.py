@@ -191,7 +191,11 @@ def main():
             kernel = "ds::fused_iteration_kernel<%s, %d, %d, false>" % (
                 tname, 16 if D <= 64 else 32 if D <= 128 else 64, 16 if dtype == "f32" else 8)
             kernel_s, launches = split["fused_ms"] / 1e3, split["fused"]
-            units_per_launch = my_pl          # one launch = one iteration over the rank's pixels
+            # one launch = one iteration over the rows the kernel updates: all of them on one GPU,
+            # all but the rows next to a neighbouring band otherwise (those go through half-sweeps)
+            fb, fe = graph.fused_rows()
+            whole = rb == 0 and re == H
+            units_per_launch = my_pl if whole else my_pl * (fe - fb) / float(re - rb)
         else:
             bytes_per_pl = 8 * elem + 1       # each phi row read once + written once, u8 cost read once
             kernel = "ds::sweep_kernel<%s, %d, false>" % (tname, 16 if D <= 64 else 32 if D <= 128 else 64)

@@ -161,6 +161,23 @@ int ds_labels(ds_handle *h, int mode, uint32_t *out);
 int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
                     int *not_empty, int *passes);
 
+/* Replaces create_array_of_epsilons before its tolerance dedup
+ * (diffusion_stereo/src/epsilon_search.rs:39-74): for the current phi, every vertex's penalty
+ * minus its pixel's minimum and every edge's penalty minus its pixel pair's minimum (each edge
+ * from both of its ends, as the reference walks them), computed in f64 in the reference's
+ * expression order, sorted ascending on the device, exact duplicates removed.  *count = how
+ * many values there are; they stay on the device until ds_epsilon_gaps_fetch copies them to
+ * out (count doubles) and releases them.  *largest_repeated (optional) = 1 if the largest
+ * value occurred more than once before the duplicates went: utils.rs:137-163 (dedup_f64)
+ * appends the last element once more when its run is longer than one, so a caller that wants
+ * the reference's array element for element applies dedup_f64 with its tolerance and, if the
+ * last value stands alone there but was repeated, appends it again.  epsilon_search.rs:84-112
+ * then runs with ds_crossing_out as the predicate.
+ * Needs H*W*D*(1+4D) doubles three times over on the device (DS_ERR_NOMEM otherwise): for
+ * images of the reference's size.  Whole-image handles only. */
+int ds_epsilon_gaps(ds_handle *h, size_t *count, int *largest_repeated);
+int ds_epsilon_gaps_fetch(ds_handle *h, double *out);
+
 /* The same computation in steps, for row bands (one handle per band; the halos of phi must be
  * current, as after ds_sweep + exchange):
  *   ds_co_begin   vertex masks and pair minima of the band's pixels (initialize_with_epsilon);

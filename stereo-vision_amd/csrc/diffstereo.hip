@@ -15,6 +15,7 @@
 #include <utility>
 #include <vector>
 
+#include "eps_sort.hpp"
 #include "kernels.hpp"
 
 namespace {
@@ -66,6 +67,9 @@ struct ds_handle {
     int *co_flags = nullptr;                          // [0] changed, [1] some pixel empty
     double co_epsilon = 0.0;
     bool co_begun = false;
+    double *eps_buf[2] = {nullptr, nullptr};          // epsilon gaps: values and the sort's second buffer
+    double *eps_sorted = nullptr;                     // one of eps_buf: sorted, duplicates removed
+    size_t eps_count = 0;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
 
@@ -163,6 +167,8 @@ void release(ds_handle *h)
     (void)hipFree(h->co_gmin);
     (void)hipFree(h->co_host_order);
     (void)hipFree(h->co_flags);
+    (void)hipFree(h->eps_buf[0]);
+    (void)hipFree(h->eps_buf[1]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -1189,6 +1195,95 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
     rc = ds_co_finish(h, lost, labels, alive_out, not_empty);
     if (rc != DS_OK) return rc;
     if (passes) *passes = done;
+    return DS_OK;
+}
+
+static void eps_release(ds_handle *h)
+{
+    (void)hipFree(h->eps_buf[0]);
+    (void)hipFree(h->eps_buf[1]);
+    h->eps_buf[0] = h->eps_buf[1] = h->eps_sorted = nullptr;
+    h->eps_count = 0;
+}
+
+int ds_epsilon_gaps(ds_handle *h, size_t *count, int *largest_repeated)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!count) return fail(h, DS_ERR_ARG, "count is NULL");
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_epsilon_gaps needs the whole image");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    eps_release(h);
+    const size_t n = (size_t)g.H * g.W * g.D * (1 + 4 * (size_t)g.D);
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+    if (n > free_b / (3 * sizeof(double)))  // two buffers + the sort's work space
+        return fail(h, DS_ERR_NOMEM, "the array of gaps (H*W*D*(1+4D) doubles, three times over) does not fit this GPU");
+    const size_t lds = (9 * (size_t)g.D + ds::kBlock) * sizeof(double);
+    for (int b = 0; b < 2; ++b) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->eps_buf[b]), n * sizeof(double));
+        if (e != hipSuccess) {
+            eps_release(h);
+            return fail_hip(h, "hipMalloc (epsilon gaps)", e);
+        }
+    }
+    const dim3 grid((unsigned)((size_t)g.H * g.W)), block(ds::kBlock);
+    if (h->dtype == DS_F64)
+        hipLaunchKernelGGL(ds::eps_gaps_kernel<double>, grid, block, lds, h->stream, g,
+                           static_cast<const double *>(h->phi), h->cost_px, h->lambda, h->eps_buf[0]);
+    else
+        hipLaunchKernelGGL(ds::eps_gaps_kernel<float>, grid, block, lds, h->stream, g,
+                           static_cast<const float *>(h->phi), h->cost_px, h->lambda, h->eps_buf[0]);
+    hipError_t e = hipGetLastError();
+    size_t unique = 0;
+    if (e == hipSuccess) e = ds::sort_unique_f64(h->eps_buf[0], h->eps_buf[1], n, &h->eps_sorted, &unique, h->stream);
+    if (e != hipSuccess) {
+        eps_release(h);
+        return fail_hip(h, "epsilon gaps", e);
+    }
+    // entries of vertices / edges that do not exist were written as +inf: one survives, last
+    if (unique > 0) {
+        double last = 0.;
+        HIPCHK(h, hipMemcpy(&last, h->eps_sorted + (unique - 1), sizeof last, hipMemcpyDeviceToHost));
+        if (std::isinf(last)) --unique;
+    }
+    // Does the largest gap occur more than once?  (The reference's dedup repeats the last
+    // element of its array in that case.)  The other buffer still holds all n values sorted:
+    // find where the +inf entries begin, by bisection, and look at the two values before.
+    int repeated = 0;
+    {
+        const double *sorted_all = h->eps_sorted == h->eps_buf[0] ? h->eps_buf[1] : h->eps_buf[0];
+        size_t lo = 0, hi = n;  // first index holding +inf lies in [lo, hi]
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo) / 2;
+            double v = 0.;
+            HIPCHK(h, hipMemcpy(&v, sorted_all + mid, sizeof v, hipMemcpyDeviceToHost));
+            if (std::isinf(v)) hi = mid;
+            else lo = mid + 1;
+        }
+        if (lo >= 2) {
+            double pair[2] = {0., 0.};
+            HIPCHK(h, hipMemcpy(pair, sorted_all + (lo - 2), sizeof pair, hipMemcpyDeviceToHost));
+            repeated = pair[0] == pair[1];
+        }
+    }
+    if (largest_repeated) *largest_repeated = repeated;
+    h->eps_count = unique;
+    *count = unique;
+    return DS_OK;
+}
+
+int ds_epsilon_gaps_fetch(ds_handle *h, double *out)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!h->eps_sorted) return fail(h, DS_ERR_STATE, "ds_epsilon_gaps_fetch without ds_epsilon_gaps");
+    if (!out && h->eps_count) return fail(h, DS_ERR_ARG, "out is NULL");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    if (h->eps_count)
+        HIPCHK(h, hipMemcpy(out, h->eps_sorted, h->eps_count * sizeof(double), hipMemcpyDeviceToHost));
+    eps_release(h);
     return DS_OK;
 }
 

@@ -1228,6 +1228,102 @@ __global__ __launch_bounds__(kBlock) void co_unpack_kernel(Geometry g, const uin
     }
 }
 
+// ---- epsilon search: every penalty gap of the graph -----------------------------------
+// Reference: diffusion_stereo/src/epsilon_search.rs:39-74 (create_array_of_epsilons before
+// its sort and dedup).  For every vertex (t, d), d <= j: f_t(d) - min_d f_t; for every
+// existing neighbour n and every existing edge (d, d'): g(d, d') - min over the pair's edges.
+// One block per pixel, f64 arithmetic in the reference's expression order whatever the
+// handle's dtype (phi is widened first), so the values equal the host restatement's bit for
+// bit.  Layout: out[(pixel * D + d) * (1 + 4 D) + 0] = vertex gap, [+ 1 + n * D + d'] = edge
+// gaps; +inf where the vertex / neighbour / edge does not exist (they sort to the end).
+// Dynamic LDS: (9 * D + kBlock) doubles.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void eps_gaps_kernel(Geometry g, const T *__restrict__ phi,
+                                                          const uint8_t *__restrict__ cost, double lambda,
+                                                          double *__restrict__ out)
+{
+    extern __shared__ double eps_lds[];
+    const int D = g.D;
+    double *own = eps_lds;            // [4][D]
+    double *nbr = own + 4 * D;        // [4][D]: the neighbour's reverse slot
+    double *f = nbr + 4 * D;          // [D]
+    double *red = f + D;              // [kBlock]
+    const double inf = __builtin_huge_val();
+    const int tid = threadIdx.x;
+    const long long pix = blockIdx.x;
+    const int i = (int)(pix / g.W), j = (int)(pix % g.W);
+    const int colour = (i + j) & 1, jc = j >> 1, il = i - g.row0 + 1;
+    const bool has[4] = {j > 0, i > 0, j + 1 < g.W, i + 1 < g.H};
+    const int ni[4] = {i, i - 1, i, i + 1}, nj[4] = {j - 1, j, j + 1, j};
+    const long long own_off = (long long)il * g.row_stride + (long long)jc * g.Dpad;
+
+    for (int e = tid; e < 4 * D; e += kBlock) {
+        const int n = e / D, d = e % D;
+        double a = 0., b = 0.;
+        if (has[n]) {
+            a = (double)phi[g.plane_off[colour][n] + own_off + d];
+            const long long off = (long long)(ni[n] - g.row0 + 1) * g.row_stride + (long long)(nj[n] >> 1) * g.Dpad;
+            b = (double)phi[g.plane_off[1 - colour][n ^ 2] + off + d];
+        }
+        own[e] = a;
+        nbr[e] = b;
+    }
+    __syncthreads();
+    auto block_min = [&](double v) {
+        red[tid] = v;
+        __syncthreads();
+        for (int w = kBlock / 2; w >= 1; w >>= 1) {
+            if (tid < w) red[tid] = fmin(red[tid], red[tid + w]);
+            __syncthreads();
+        }
+        const double m = red[0];
+        __syncthreads();
+        return m;
+    };
+    // vertices (diffusion_graph.rs:99-122, 456-470)
+    double vmin = inf;
+    for (int d = tid; d < D; d += kBlock) {
+        double v = inf;
+        if (d <= j) {
+            double sum = 0.;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (has[n]) sum += own[n * D + d];
+            const double q = (double)cost[colour * g.cost_colour_stride + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d];
+            v = q - sum;
+        }
+        f[d] = v;
+        vmin = fmin(vmin, v);
+    }
+    vmin = block_min(vmin);
+    const long long stride = 1 + 4LL * D;
+    double *dst = out + pix * D * stride;
+    for (int d = tid; d < D; d += kBlock) dst[d * stride] = d <= j ? f[d] - vmin : inf;
+    // edges (diffusion_graph.rs:135-141, 152-169, 480-494)
+    for (int n = 0; n < 4; ++n) {
+        auto exists = [&](int d, int nd) {
+            if (!has[n] || d > j || nd > nj[n]) return false;
+            if (n == 2 && nd > d + 1) return false;
+            if (n == 0 && d > nd + 1) return false;
+            return true;
+        };
+        auto penalty = [&](int d, int nd) {
+            const double dist = d > nd ? (double)(d - nd) : (double)(nd - d);
+            return lambda * dist + own[n * D + d] + nbr[n * D + nd];
+        };
+        double emin = inf;
+        for (int e = tid; e < D * D; e += kBlock) {
+            const int d = e / D, nd = e % D;
+            if (exists(d, nd)) emin = fmin(emin, penalty(d, nd));
+        }
+        emin = block_min(emin);
+        for (int e = tid; e < D * D; e += kBlock) {
+            const int d = e / D, nd = e % D;
+            dst[d * stride + 1 + n * D + nd] = exists(d, nd) ? penalty(d, nd) - emin : inf;
+        }
+    }
+}
+
 // ---- stage 1: cost volume --------------------------------------------------------------
 // cost[d][r][j] = |L[i][j] - R[i][j-d]| for d <= j, else 0; r = band row, i = row0 + r.
 // One thread per 4 consecutive bytes of the label-major volume: lanes run along j, so

@@ -41,6 +41,8 @@ SYMBOLS = {
     "ds_energy": (_I, [_P, _DP, _DP]),
     "ds_labels": (_I, [_P, _I, _P]),
     "ds_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
+    "ds_epsilon_gaps": (_I, [_P, C.POINTER(C.c_size_t), _IP]),
+    "ds_epsilon_gaps_fetch": (_I, [_P, _P]),
     "ds_co_begin": (_I, [_P, _D]),
     "ds_co_pass": (_I, [_P, _IP, _IP]),
     "ds_co_halo": (_I, [_P, _I, _I, _I, _PP, C.POINTER(C.c_size_t)]),
@@ -203,6 +205,31 @@ class DiffusionGraph:
         if with_mask:
             out["alive"] = alive
         return out
+
+    def epsilon_gaps(self, with_flag=False):
+        """create_array_of_epsilons before its tolerance dedup (epsilon_search.rs:39-74): all
+        vertex and edge penalty gaps of the current phi, sorted, exact duplicates removed (f64).
+        with_flag: also whether the largest value occurred more than once."""
+        n, rep = C.c_size_t(), C.c_int()
+        self._chk(lib().ds_epsilon_gaps(self._h, C.byref(n), C.byref(rep)))
+        out = np.empty(n.value, dtype=np.float64)
+        self._chk(lib().ds_epsilon_gaps_fetch(self._h, _ptr(out) if n.value else None))
+        return (out, bool(rep.value)) if with_flag else out
+
+    def create_array_of_epsilons(self, tolerance):
+        """epsilon_search.rs:39-74 element for element: the gaps, then utils.rs:137-163."""
+        gaps, repeated = self.epsilon_gaps(with_flag=True)
+        out, i = [], 0
+        while i < len(gaps):
+            out.append(float(gaps[i]))
+            j = i + 1
+            while j < len(gaps) and not abs(gaps[i] - gaps[j]) > tolerance:
+                j += 1
+            last_run = j - i if j == len(gaps) else 0
+            i = j
+        if len(gaps) and (last_run > 1 or repeated):
+            out.append(float(gaps[-1]))
+        return np.asarray(out, dtype=np.float64)
 
     # crossing-out in steps (row bands; see include/diffstereo.h)
     def co_begin(self, epsilon):

@@ -283,6 +283,18 @@ bool DiffusionGraph::crossing_out_on_device(double epsilon, std::vector<std::uin
     return not_empty != 0;
 }
 
+std::vector<double> DiffusionGraph::epsilon_gaps_on_device(bool &largest_repeated)
+{
+    push();
+    std::size_t count = 0;
+    int repeated = 0;
+    check(ds_epsilon_gaps(h_, &count, &repeated));
+    std::vector<double> gaps(count);
+    check(ds_epsilon_gaps_fetch(h_, gaps.data()));
+    largest_repeated = repeated != 0;
+    return gaps;
+}
+
 void DiffusionGraph::build_depth_map(std::size_t iteration)
 {
     pgm_writer(depth_map(), "./images/results/result_" + std::to_string(iteration) + ".pgm", max_disparity);

@@ -67,6 +67,10 @@ public:
     // (crossing_out_graph.rs:67-183) on the device; vertices[i][j][d] is the resulting
     // vertex mask.  Returns is_not_empty() (:187-193).
     bool crossing_out_on_device(double epsilon, std::vector<std::uint8_t> &vertices, int *passes = nullptr);
+    // All vertex and edge penalty gaps of the graph (epsilon_search.rs:39-74), computed and
+    // sorted on the GPU, exact duplicates removed; largest_repeated: the largest one occurred
+    // more than once (ds_epsilon_gaps).
+    std::vector<double> epsilon_gaps_on_device(bool &largest_repeated);
 
 private:
     DiffusionGraph() = default;

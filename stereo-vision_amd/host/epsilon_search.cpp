@@ -9,6 +9,28 @@ namespace stereo {
 std::vector<double> create_array_of_epsilons(CrossingOutGraph &crossing_out_graph, double tolerance)
 {
     DiffusionGraph &g = crossing_out_graph.diffusion_graph;
+    if (crossing_out_graph.on_device()) {
+        // The gaps come from the GPU already sorted and without exact duplicates.  dedup_f64
+        // repeats the array's last element when its run is longer than one value: a run of
+        // exact duplicates of the largest gap is no longer visible here, the flag stands for it.
+        bool largest_repeated = false;
+        const std::vector<double> gaps = g.epsilon_gaps_on_device(largest_repeated);
+        std::vector<double> unique_values = dedup_f64(gaps, tolerance);
+        if (!gaps.empty() && largest_repeated) {
+            std::size_t run_start = gaps.size() - 1;  // first element of the last kept run
+            {
+                std::size_t i = 0;
+                while (i < gaps.size()) {
+                    run_start = i;
+                    std::size_t j = i + 1;
+                    while (j < gaps.size() && approx_equal(gaps[i], gaps[j], tolerance)) ++j;
+                    i = j;
+                }
+            }
+            if (run_start == gaps.size() - 1) unique_values.push_back(gaps.back());
+        }
+        return unique_values;
+    }
     const std::size_t height = g.height(), width = g.width(), max_disparity = g.max_disparity;
     std::vector<double> array;
     for (std::size_t i = 0; i < height; ++i)

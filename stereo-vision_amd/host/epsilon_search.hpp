@@ -3,8 +3,9 @@
 //
 // The array of gaps has one entry per vertex and per existing edge (O(H*W*4*D^2) values), so
 // building it is for small images, as in the reference (which leaves the search disabled in
-// its main).  The search itself runs the crossing-out of the graph's mode: on the device for a
-// CrossingOutGraph in device mode, on the host masks otherwise.
+// its main).  Both the array and the search follow the graph's mode: for a CrossingOutGraph in
+// device mode the gaps are computed and sorted on the GPU (ds_epsilon_gaps) and the search runs
+// the GPU crossing-out; otherwise host loops and host masks.
 #pragma once
 #include <vector>
 

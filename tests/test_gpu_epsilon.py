@@ -1,0 +1,75 @@
+"""ds_epsilon_gaps (create_array_of_epsilons of diffusion_stereo/src/epsilon_search.rs:39-74 on
+the GPU) against the oracle's restatement on the same potentials: the same set of values,
+bit for bit, and the same epsilon out of the binary search."""
+import os
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import pyoracle
+from tests.util import random_pair, random_phi
+
+pytestmark = pytest.mark.gpu
+
+
+def _graphs(H, W, D, dtype, seed, iters=0):
+    load_package()
+    from stereo_vision_amd import diffstereo
+    left, right = random_pair(H, W, seed=seed)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    # the oracle always in f64: the library widens f32 potentials and computes the gaps in f64
+    o = pyoracle.OracleGraph(left.astype(np.uint32), right.astype(np.uint32), D, 1.2)
+    if iters:
+        g.iterate(iters)
+        phi = g.get_phi()
+    else:
+        phi = random_phi(H, W, D, dtype, seed=seed + 1)
+        g.set_phi(phi)
+    o.set_potentials(np.asarray(phi, dtype=np.float64))
+    return g, o
+
+
+@pytest.mark.parametrize("H,W,D,dtype", [(5, 5, 40, "f64"), (6, 9, 5, "f64"), (4, 11, 8, "f32"),
+                                         (3, 2, 3, "f64"), (1, 7, 4, "f64"), (7, 1, 4, "f32"),
+                                         (5, 13, 17, "f64")])
+def test_gaps_match_oracle(H, W, D, dtype):
+    g, o = _graphs(H, W, D, dtype, seed=H * 100 + W)
+    got = g.epsilon_gaps()
+    want = np.unique(o.create_array_of_epsilons(0.0))
+    assert got.dtype == np.float64 and np.all(np.diff(got) > 0) and np.all(np.isfinite(got))
+    assert np.array_equal(got, want)
+    # with the reference's tolerance dedup: the reference's array element for element
+    for tol in (0.0, 1e-9, 0.5):
+        assert np.array_equal(g.create_array_of_epsilons(tol), o.create_array_of_epsilons(tol))
+    g.close()
+
+
+def test_gaps_after_diffusion_and_search():
+    """After real iterations: same array, and the binary search over it with the GPU
+    crossing-out as predicate finds the oracle's epsilon."""
+    g, o = _graphs(5, 9, 6, "f64", seed=3, iters=30)
+    got = g.epsilon_gaps()
+    assert np.array_equal(got, np.unique(o.create_array_of_epsilons(0.0)))
+    array = pyoracle.dedup_f64(got, 1e-9)
+    o.co_alloc(True)
+    want = o.epsilon_search(o.create_array_of_epsilons(1e-9))
+    first, last = 0, len(array) - 1
+    while first < last:                       # epsilon_search.rs:84-112
+        median = (first + last) // 2
+        if g.crossing_out(array[median])["not_empty"]:
+            last = median
+        else:
+            first = median + 1
+    assert array[(first + last) // 2] == want
+    g.close()
+
+
+def test_gaps_need_the_whole_image():
+    load_package()
+    from stereo_vision_amd import diffstereo
+    left, right = random_pair(8, 8, seed=1)
+    g = diffstereo.DiffusionGraph(left, right, 4, 1.2, dtype="f64", row_begin=2, row_end=6)
+    with pytest.raises(diffstereo.DiffStereoError):
+        g.epsilon_gaps()
+    g.close()
