@@ -53,8 +53,9 @@ class HipBandEngine:
         self.H = graph.H
         self.stage = stage_through_host  # gloo rehearsal: halos travel via pinned host copies
         self._views = {}
-        # A main stream of its own, not the device's default stream: work queued on the default
-        # stream waits for every other stream, which would serialise the side stream with it.
+        # A main stream of the engine's own rather than whatever stream is current when the
+        # engine is made: the two streams below are then ordered by this class's events alone
+        # (the legacy default stream would add its implicit synchronisation with blocking streams).
         self.main = torch.cuda.Stream()
         self.main.wait_stream(torch.cuda.current_stream())
         # boundary rows + exchanges beside the interior kernel.  Normal priority on purpose: with a
