@@ -528,9 +528,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Geometry g, T *__restrict
     T *dst[4] = {phi + pm[0] + rowbase, phi + pm[1] + rowbase, phi + pm[2] + rowbase, phi + pm[3] + rowbase};
     const uint8_t *cost_row = cost_c + (long long)(il - 1) * g.Wh * g.Dpad;
     const unsigned lane_off = (unsigned)(q * g.Dpad + d0);
-    // D a multiple of 4 (no padding labels inside a lane's vector); lanes beyond D stay idle
-    const bool rows_interior = i > 0 && i + 1 < g.H && g.D == g.Dpad;
-    const bool lane_on = d0 < g.D;
+    const bool rows_interior = i > 0 && i + 1 < g.H && g.D == 4 * LPP;
 
     const int seg0 = blockIdx.x * seg_pixels;
     const int groups = seg_pixels / PPW;  // host guarantees divisibility
@@ -541,22 +539,19 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Geometry g, T *__restrict
         if (rows_interior && jmin >= g.D && jmax + 1 < g.W) {
             const unsigned off = (unsigned)(jc0 * g.Dpad) + lane_off;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) psi[n] = lane_on ? ld4_nt(src[n] + off) : splat(Real<T>::inf());
-            const V4<T> qc = unpack_cost<T>(
-                lane_on ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cost_row + off)) : 0u);
+            for (int n = 0; n < 4; ++n) psi[n] = ld4_nt(src[n] + off);
+            const V4<T> qc = unpack_cost<T>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cost_row + off)));
             messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
             V4<T> avg;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 avg.v[k] = (qc.v[k] + (((M[0].v[k] + M[1].v[k]) + M[2].v[k]) + M[3].v[k])) * T(0.25);
-            if (lane_on) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    V4<T> out;
+            for (int n = 0; n < 4; ++n) {
+                V4<T> out;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) out.v[k] = avg.v[k] - M[n].v[k];
-                    st4_nt(dst[n] + off, out);
-                }
+                for (int k = 0; k < 4; ++k) out.v[k] = avg.v[k] - M[n].v[k];
+                st4_nt(dst[n] + off, out);
             }
         } else {
             update_pixel<T, LPP>(g, phi, cost_c, colour, locate(g, i, s, jc0 + q, d0), lam, lambda, lseg, lane);
@@ -649,11 +644,7 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
     const int a = c0 - 1 + 2 * kp;  // first column of the slot's pair (odd)
     const int r0 = row_begin + blockIdx.y * rows_per_seg;
     const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
-    // Fast path: D a multiple of 4 and every pixel of the strip has all D labels.  With D below
-    // the lanes' 4 * LPP labels the upper lanes stay idle: they load nothing, carry +inf and
-    // store nothing.
-    const bool cols_interior = g.D == g.Dpad && c0 - 1 >= g.D && c0 + FC + 1 < g.W;
-    const bool lane_on = d0 < g.D, ragged = g.D != DL;
+    const bool cols_interior = g.D == DL && c0 - 1 >= g.D && c0 + FC + 1 < g.W;
     const uint8_t *cost_red = cost, *cost_black = cost + g.cost_colour_stride;
 
     // what fetch() keeps for produce(): the four neighbour rows and the packed cost word (the
@@ -677,11 +668,9 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
             const long long nb[4] = {own + (long long)(p - 1) * g.Dpad, own - g.row_stride,
                                      own + (long long)p * g.Dpad, own + g.row_stride};
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                pre_psi[n] = lane_on ? ld4_nt(phi + g.plane_off[1][n ^ 2] + nb[n]) : splat(inf);
-            pre_cost = lane_on ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
-                                     cost_red + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0))
-                               : 0u;
+            for (int n = 0; n < 4; ++n) pre_psi[n] = ld4_nt(phi + g.plane_off[1][n ^ 2] + nb[n]);
+            pre_cost = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                cost_red + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0));
         } else {
             const Pixel px = red_pixel(r);
             load_psi(g, phi, 1, px, pre_psi);
@@ -706,10 +695,6 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
                 const T avg = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * T(0.25);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) out[n].v[c] = avg - M[n].v[c];
-            }
-            if (ragged) {  // idle lanes hold inf - inf: hand +inf on instead
-#pragma unroll
-                for (int n = 0; n < 4; ++n) out[n] = pick(lane_on, out[n], splat(inf));
             }
         } else {
             const Pixel px = red_pixel(r);
@@ -746,24 +731,20 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
             psi[1] = down_prev;
             psi[2] = pick(p != 0, across, side_cur);
             psi[3] = up_next;
-            const V4<T> qc = unpack_cost<T>(
-                lane_on ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
-                              cost_black + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0))
-                        : 0u);
+            const V4<T> qc = unpack_cost<T>(__builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                cost_black + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0)));
             messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
             const long long own = (long long)il * g.row_stride + (long long)jc * g.Dpad + d0;
             V4<T> avg;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 avg.v[c] = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * T(0.25);
-            if (lane_on) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    V4<T> out;
+            for (int n = 0; n < 4; ++n) {
+                V4<T> out;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) out.v[c] = avg.v[c] - M[n].v[c];
-                    st4_nt(phi + np.out_off[n] + own, out);
-                }
+                for (int c = 0; c < 4; ++c) out.v[c] = avg.v[c] - M[n].v[c];
+                st4_nt(phi + np.out_off[n] + own, out);
             }
         } else {
             Pixel px = locate(g, i, (i + 1) & 1, jc, d0);
