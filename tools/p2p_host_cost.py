@@ -23,6 +23,13 @@ H, W, D = 2160, 3840, 256
 left, right, _ = synth.synthetic_pair(H, W, D)
 rb, re = bands.partition_rows(H, 8)[3]
 g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32", row_begin=rb, row_end=re)
+# DUMMY_STREAMS=n: n more streams that have run work, created before the engine's two, to see
+# whether the engine's streams still overlap when streams outnumber the hardware queues
+dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("DUMMY_STREAMS", "0")))]
+for st in dummies:
+    with torch.cuda.stream(st):
+        torch.zeros(8, device="cuda").add_(1)
+torch.cuda.synchronize()
 eng = bands.HipBandEngine(g)
 runner = bands.BandRunner(eng, rank=0, world=1)
 runner.up = runner.down = 0      # loop the exchange back to this rank
