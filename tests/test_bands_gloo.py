@@ -43,6 +43,9 @@ def _free_port():
 
 
 def _worker(rank, world, port, H, W, D, iters, out):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(240, exit=True, file=sys.stderr)  # a stuck rank ends itself
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -80,6 +83,9 @@ def test_bands_over_gloo_match_single_process(world, H):
 
 
 def _co_worker(rank, world, port, H, W, D, iters, eps, out):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(240, exit=True, file=sys.stderr)  # a stuck rank ends itself
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -28,6 +28,9 @@ def _free_port():
 
 
 def _worker(rank, port, dtype, D, out):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(240, exit=True, file=sys.stderr)  # a stuck rank ends itself
     import torch
     import torch.distributed as dist
     load_package()
