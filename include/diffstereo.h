@@ -178,6 +178,14 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
 int ds_epsilon_gaps(ds_handle *h, size_t *count, int *largest_repeated);
 int ds_epsilon_gaps_fetch(ds_handle *h, double *out);
 
+/* Replaces dedup_f64 (diffusion_stereo/src/utils.rs:137-163) for what ds_epsilon_gaps returns;
+ * host code only, no handle.  sorted[0..n) ascending; out receives the first value of every run
+ * of values within `tolerance` of that first value (utils.rs:109-114: not |x - y| > tolerance)
+ * and then the last value once more if its run is longer than one value or largest_repeated is
+ * set (the flag of ds_epsilon_gaps: exact duplicates of the largest value were removed on the
+ * device).  out needs room for n + 1 values; *n_out = how many were written. */
+int ds_dedup_gaps(const double *sorted, size_t n, double tolerance, int largest_repeated, double *out, size_t *n_out);
+
 /* The same computation in steps, for row bands (one handle per band; the halos of phi must be
  * current, as after ds_sweep + exchange):
  *   ds_co_begin   vertex masks and pair minima of the band's pixels (initialize_with_epsilon);

@@ -1287,6 +1287,23 @@ int ds_epsilon_gaps_fetch(ds_handle *h, double *out)
     return DS_OK;
 }
 
+int ds_dedup_gaps(const double *sorted, size_t n, double tolerance, int largest_repeated, double *out, size_t *n_out)
+{
+    if (!n_out || (n && (!sorted || !out))) return DS_ERR_ARG;
+    size_t kept = 0, i = 0, run_start = 0;
+    while (i < n) {
+        out[kept++] = sorted[i];
+        run_start = i;
+        size_t j = i + 1;
+        while (j < n && !(std::fabs(sorted[i] - sorted[j]) > tolerance)) ++j;
+        i = j;
+    }
+    // the reference pushes the array's last element once more when its run is longer than one
+    if (n && (run_start != n - 1 || largest_repeated)) out[kept++] = sorted[n - 1];
+    *n_out = kept;
+    return DS_OK;
+}
+
 int ds_placement_info(const ds_handle *h, int *tries, double *probe_ms, int *split)
 {
     if (!h) return DS_ERR_ARG;

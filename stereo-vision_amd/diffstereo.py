@@ -43,6 +43,7 @@ SYMBOLS = {
     "ds_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
     "ds_epsilon_gaps": (_I, [_P, C.POINTER(C.c_size_t), _IP]),
     "ds_epsilon_gaps_fetch": (_I, [_P, _P]),
+    "ds_dedup_gaps": (_I, [_P, C.c_size_t, _D, _I, _P, C.POINTER(C.c_size_t)]),
     "ds_co_begin": (_I, [_P, _D]),
     "ds_co_pass": (_I, [_P, _IP, _IP]),
     "ds_co_halo": (_I, [_P, _I, _I, _I, _PP, C.POINTER(C.c_size_t)]),
@@ -219,17 +220,11 @@ class DiffusionGraph:
     def create_array_of_epsilons(self, tolerance):
         """epsilon_search.rs:39-74 element for element: the gaps, then utils.rs:137-163."""
         gaps, repeated = self.epsilon_gaps(with_flag=True)
-        out, i = [], 0
-        while i < len(gaps):
-            out.append(float(gaps[i]))
-            j = i + 1
-            while j < len(gaps) and not abs(gaps[i] - gaps[j]) > tolerance:
-                j += 1
-            last_run = j - i if j == len(gaps) else 0
-            i = j
-        if len(gaps) and (last_run > 1 or repeated):
-            out.append(float(gaps[-1]))
-        return np.asarray(out, dtype=np.float64)
+        out = np.empty(len(gaps) + 1, dtype=np.float64)
+        n = C.c_size_t()
+        self._chk(lib().ds_dedup_gaps(_ptr(gaps) if len(gaps) else None, len(gaps), float(tolerance),
+                                     int(repeated), _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
 
     # crossing-out in steps (row bands; see include/diffstereo.h)
     def co_begin(self, epsilon):

@@ -1,5 +1,7 @@
 #include "epsilon_search.hpp"
 
+#include "diffstereo.h"
+
 #include <algorithm>
 #include <cstdio>
 #include <stdexcept>
@@ -10,25 +12,16 @@ std::vector<double> create_array_of_epsilons(CrossingOutGraph &crossing_out_grap
 {
     DiffusionGraph &g = crossing_out_graph.diffusion_graph;
     if (crossing_out_graph.on_device()) {
-        // The gaps come from the GPU already sorted and without exact duplicates.  dedup_f64
-        // repeats the array's last element when its run is longer than one value: a run of
-        // exact duplicates of the largest gap is no longer visible here, the flag stands for it.
+        // The gaps come from the GPU already sorted and without exact duplicates; the library's
+        // ds_dedup_gaps is dedup_f64 for that form (it knows whether the largest gap was repeated,
+        // which decides whether the reference's dedup pushes the last element once more).
         bool largest_repeated = false;
         const std::vector<double> gaps = g.epsilon_gaps_on_device(largest_repeated);
-        std::vector<double> unique_values = dedup_f64(gaps, tolerance);
-        if (!gaps.empty() && largest_repeated) {
-            std::size_t run_start = gaps.size() - 1;  // first element of the last kept run
-            {
-                std::size_t i = 0;
-                while (i < gaps.size()) {
-                    run_start = i;
-                    std::size_t j = i + 1;
-                    while (j < gaps.size() && approx_equal(gaps[i], gaps[j], tolerance)) ++j;
-                    i = j;
-                }
-            }
-            if (run_start == gaps.size() - 1) unique_values.push_back(gaps.back());
-        }
+        std::vector<double> unique_values(gaps.size() + 1);
+        std::size_t kept = 0;
+        if (ds_dedup_gaps(gaps.data(), gaps.size(), tolerance, largest_repeated ? 1 : 0, unique_values.data(), &kept) != 0)
+            throw std::runtime_error("ds_dedup_gaps failed");
+        unique_values.resize(kept);
         return unique_values;
     }
     const std::size_t height = g.height(), width = g.width(), max_disparity = g.max_disparity;
