@@ -161,6 +161,19 @@ int ds_labels(ds_handle *h, int mode, uint32_t *out);
 int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
                     int *not_empty, int *passes);
 
+/* Replaces CrossingOutGraph::find_best_labeling (diffusion_stereo/src/crossing_out_graph.rs:
+ * 349-364, with min_vertex_between_existing :284-300 and cross_vertex :336-345) on the masks the
+ * handle holds after ds_crossing_out (or ds_co_begin + ds_co_pass to the fixed point) for the
+ * phi they were made from: pixels in raster order; each keeps, of its alive labels, the one with
+ * the smallest f_t(d) (f64, the first of equals), its other labels are crossed out and the masks
+ * are relaxed to their fixed point again (at most max_passes passes each time) before the next
+ * pixel is looked at.  labels: [H][W].  *not_empty = 0 where the reference panics ("Graph is
+ * empty", or a pixel without labels): labels of the pixels after that one are then not
+ * meaningful.  *choices (optional) = pixels that still had more than one label when their turn
+ * came.  Sequential by definition: one small launch per such pixel plus its relaxation passes;
+ * pixels with one label left are walked through on the device.  Whole-image handles only. */
+int ds_find_best_labeling(ds_handle *h, int max_passes, uint32_t *labels, int *not_empty, long long *choices);
+
 /* Replaces create_array_of_epsilons before its tolerance dedup
  * (diffusion_stereo/src/epsilon_search.rs:39-74): for the current phi, every vertex's penalty
  * minus its pixel's minimum and every edge's penalty minus its pixel pair's minimum (each edge

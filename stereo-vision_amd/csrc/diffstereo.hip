@@ -65,6 +65,7 @@ struct ds_handle {
     void *co_gmin = nullptr;                          // [2][Hb][Wh][4] min edge penalty per (pixel, slot)
     uint8_t *co_host_order = nullptr;                 // [Hb][W][D], only when the mask is asked for
     int *co_flags = nullptr;                          // [0] changed, [1] some pixel empty
+    long long *co_state = nullptr;                    // co_fix_kernel's report, [2]
     double co_epsilon = 0.0;
     bool co_begun = false;
     double *eps_buf[2] = {nullptr, nullptr};          // epsilon gaps: values and the sort's second buffer
@@ -167,6 +168,7 @@ void release(ds_handle *h)
     (void)hipFree(h->co_gmin);
     (void)hipFree(h->co_host_order);
     (void)hipFree(h->co_flags);
+    (void)hipFree(h->co_state);
     (void)hipFree(h->eps_buf[0]);
     (void)hipFree(h->eps_buf[1]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1195,6 +1197,66 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
     rc = ds_co_finish(h, lost, labels, alive_out, not_empty);
     if (rc != DS_OK) return rc;
     if (passes) *passes = done;
+    return DS_OK;
+}
+
+int ds_find_best_labeling(ds_handle *h, int max_passes, uint32_t *labels, int *not_empty, long long *choices)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!labels || !not_empty) return fail(h, DS_ERR_ARG, "labels / not_empty is NULL");
+    if (max_passes < 1) return fail(h, DS_ERR_ARG, "max_passes must be >= 1");
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_find_best_labeling needs the whole image");
+    if (!h->co_begun)
+        return fail(h, DS_ERR_STATE, "ds_find_best_labeling works on the masks of ds_crossing_out (or ds_co_begin + ds_co_pass)");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    if (!h->co_state) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->co_state), 2 * sizeof(long long));
+        if (e != hipSuccess) return fail_hip(h, "hipMalloc(labeling state)", e);
+    }
+    const long long total = (long long)g.H * g.W;
+    long long next = 0, chosen = 0;
+    int ok = 1;
+    while (next < total) {
+        // a launch walks at most 2^20 pixels, so that no single launch runs for seconds
+        if (h->dtype == DS_F64)
+            hipLaunchKernelGGL(ds::co_fix_kernel<double>, dim3(1), dim3(64), 0, h->stream, g,
+                               static_cast<const double *>(h->phi), h->cost_px, h->co_alive, next, 1LL << 20,
+                               h->d_labels, h->co_state);
+        else
+            hipLaunchKernelGGL(ds::co_fix_kernel<float>, dim3(1), dim3(64), 0, h->stream, g,
+                               static_cast<const float *>(h->phi), h->cost_px, h->co_alive, next, 1LL << 20,
+                               h->d_labels, h->co_state);
+        HIPCHK(h, hipGetLastError());
+        long long st[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(st, h->co_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        next = st[1];
+        if (st[0] == 2) {  // a pixel without labels: the reference's "Disparity ... wasn't found"
+            ok = 0;
+            break;
+        }
+        if (st[0] == 1) {  // labels were crossed out: back to the fixed point (crossing_out, :135-183)
+            ++chosen;
+            int changed = 1, lost = 0, done = 0;
+            while (changed && !lost && done < max_passes) {
+                rc = ds_co_pass(h, &changed, &lost);
+                if (rc != DS_OK) return rc;
+                ++done;
+            }
+            if (changed && !lost)
+                return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
+            if (lost) {    // the reference's assert!(is_not_empty)
+                ok = 0;
+                break;
+            }
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(labels, h->d_labels, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *not_empty = ok;
+    if (choices) *choices = chosen;
     return DS_OK;
 }
 

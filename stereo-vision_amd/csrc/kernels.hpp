@@ -1228,6 +1228,85 @@ __global__ __launch_bounds__(kBlock) void co_unpack_kernel(Geometry g, const uin
     }
 }
 
+// ---- find_best_labeling: fix one label per pixel, in raster order ------------------------
+// Reference: diffusion_stereo/src/crossing_out_graph.rs:284-300 (min_vertex_between_existing),
+// :336-345 (cross_vertex), :349-364 (find_best_labeling).  One wavefront walks the pixels from
+// `first` on.  A pixel with a single alive label keeps it (crossing out its other labels is a
+// no-op, and the crossing-out that follows changes nothing).  At the first pixel with several
+// alive labels it chooses the one with the smallest f_t(d) (f64 in the reference's expression
+// order, the first of equals), deletes the others and stops: the caller relaxes the masks to
+// their fixed point again and relaunches from the next pixel.
+// state[0] = 0: walked to the end of the image (or through `budget` pixels), 1: deleted labels
+// at pixel state[1] - 1, 2: pixel state[1] has no alive label; state[1] = next pixel to look at.
+template <typename T>
+__global__ __launch_bounds__(64) void co_fix_kernel(Geometry g, const T *__restrict__ phi,
+                                                    const uint8_t *__restrict__ cost, uint8_t *alive,
+                                                    long long first, long long budget,
+                                                    uint32_t *__restrict__ labels, long long *__restrict__ state)
+{
+    const int lane = threadIdx.x, d0 = 4 * lane;
+    const long long total = (long long)g.H * g.W;
+    const double inf = __builtin_huge_val();
+    long long idx = first;
+    for (long long step = 0; idx < total && step < budget; ++step, ++idx) {
+        const int i = (int)(idx / g.W), j = (int)(idx % g.W);
+        const int colour = (i + j) & 1, jc = j >> 1;
+        const long long in_colour = ((long long)(i - g.row0) * g.Wh + jc) * g.Dpad + d0;
+        uint8_t *mask = mask_base(g, alive, colour) + in_colour;
+        const uint32_t bits = d0 < g.Dpad ? *reinterpret_cast<const volatile uint32_t *>(mask) & 0x01010101u : 0u;
+        int count = __popc(bits), lowest = 0x7fffffff;
+#pragma unroll
+        for (int k = 3; k >= 0; --k)
+            if ((bits >> (8 * k)) & 1u) lowest = d0 + k;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            count += __shfl_xor(count, m);
+            const int o = __shfl_xor(lowest, m);
+            lowest = o < lowest ? o : lowest;
+        }
+        if (count == 0) {
+            if (lane == 0) { state[0] = 2; state[1] = idx; }
+            return;
+        }
+        if (count == 1) {
+            if (lane == 0) labels[idx] = (uint32_t)lowest;
+            continue;
+        }
+        // several alive labels: smallest f_t(d) = q_t(d) - sum_n phi[t][n][d], first of equals
+        const bool has[4] = {j > 0, i > 0, j + 1 < g.W, i + 1 < g.H};
+        const long long own = (long long)(i - g.row0 + 1) * g.row_stride + (long long)jc * g.Dpad + d0;
+        double best = inf;
+        int best_d = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((bits >> (8 * k)) & 1u)) continue;
+            double sum = 0.;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (has[n]) sum += (double)phi[g.plane_off[colour][n] + own + k];
+            const double f = (double)cost[colour * g.cost_colour_stride + in_colour + k] - sum;
+            if (f < best) { best = f; best_d = d0 + k; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double of = __shfl_xor(best, m);
+            const int od = __shfl_xor(best_d, m);
+            if (of < best || (of == best && od < best_d)) { best = of; best_d = od; }
+        }
+        if (d0 < g.Dpad) {
+            const uint32_t keep = (best_d >= d0 && best_d < d0 + 4) ? 1u << (8 * (best_d - d0)) : 0u;
+            *reinterpret_cast<volatile uint32_t *>(mask) = keep;
+        }
+        if (lane == 0) {
+            labels[idx] = (uint32_t)best_d;
+            state[0] = 1;
+            state[1] = idx + 1;
+        }
+        return;
+    }
+    if (lane == 0) { state[0] = 0; state[1] = idx; }
+}
+
 // ---- epsilon search: every penalty gap of the graph -----------------------------------
 // Reference: diffusion_stereo/src/epsilon_search.rs:39-74 (create_array_of_epsilons before
 // its sort and dedup).  For every vertex (t, d), d <= j: f_t(d) - min_d f_t; for every

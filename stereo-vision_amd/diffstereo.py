@@ -41,6 +41,7 @@ SYMBOLS = {
     "ds_energy": (_I, [_P, _DP, _DP]),
     "ds_labels": (_I, [_P, _I, _P]),
     "ds_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
+    "ds_find_best_labeling": (_I, [_P, _I, _P, _IP, C.POINTER(C.c_longlong)]),
     "ds_epsilon_gaps": (_I, [_P, C.POINTER(C.c_size_t), _IP]),
     "ds_epsilon_gaps_fetch": (_I, [_P, _P]),
     "ds_dedup_gaps": (_I, [_P, C.c_size_t, _D, _I, _P, C.POINTER(C.c_size_t)]),
@@ -206,6 +207,14 @@ class DiffusionGraph:
         if with_mask:
             out["alive"] = alive
         return out
+
+    def find_best_labeling(self, max_passes=100000):
+        """crossing_out_graph.rs:349-364 on the masks left by crossing_out(): one label per pixel,
+        fixed in raster order with a crossing-out after each choice.  dict(labels, not_empty, choices)."""
+        labels = np.empty((self.rows, self.W), dtype=np.uint32)
+        ne, n = C.c_int(), C.c_longlong()
+        self._chk(lib().ds_find_best_labeling(self._h, int(max_passes), _ptr(labels), C.byref(ne), C.byref(n)))
+        return {"labels": labels, "not_empty": bool(ne.value), "choices": n.value}
 
     def epsilon_gaps(self, with_flag=False):
         """create_array_of_epsilons before its tolerance dedup (epsilon_search.rs:39-74): all

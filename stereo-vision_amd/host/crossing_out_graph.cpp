@@ -107,7 +107,10 @@ bool CrossingOutGraph::is_not_empty() const
 
 bool CrossingOutGraph::consistent_with_epsilon(double epsilon)
 {
-    if (on_device_) return diffusion_graph.crossing_out_on_device(epsilon, vertices_);
+    if (on_device_) {
+        device_masks_ = true;
+        return diffusion_graph.crossing_out_on_device(epsilon, vertices_);
+    }
     initialize_with_epsilon(epsilon);
     crossing_out();
     return is_not_empty();
@@ -158,6 +161,7 @@ std::size_t CrossingOutGraph::diffusion_while_not_consistent(double epsilon, std
         if (on_device_) {
             int passes = 0;
             const bool ok = diffusion_graph.crossing_out_on_device(epsilon, vertices_, &passes);
+            device_masks_ = true;
             if (verbose) std::printf("Crossing out is done (%d passes on the device)\n", passes);
             if (ok) {
                 if (verbose) std::printf("Graph is consistent. Diffusion is done\n");
@@ -228,7 +232,20 @@ void CrossingOutGraph::cross_vertex(std::size_t i, std::size_t j, std::size_t di
 
 Matrix CrossingOutGraph::find_best_labeling()
 {
-    need_host_masks("find_best_labeling");
+    if (on_device_) {
+        // The masks live on the GPU since the last consistent_with_epsilon /
+        // diffusion_while_not_consistent.  Without one, every vertex and edge is alive, as
+        // initialize() leaves them: an epsilon no gap reaches gives the device that state.
+        if (!device_masks_) diffusion_graph.crossing_out_on_device(1e30, vertices_);
+        device_masks_ = true;
+        bool not_empty = false;
+        Matrix m = diffusion_graph.find_best_labeling_on_device(not_empty);
+        if (!not_empty) throw std::runtime_error("Graph is empty");
+        for (std::size_t i = 0; i < H_; ++i)
+            for (std::size_t j = 0; j < W_; ++j)
+                for (std::size_t d = 0; d < D_; ++d) set_vertex(i, j, d, d == m[i][j]);
+        return m;
+    }
     Matrix m(H_, std::vector<std::size_t>(W_, 0));
     for (std::size_t i = 0; i < H_; ++i)
         for (std::size_t j = 0; j < W_; ++j) {

@@ -2,10 +2,10 @@
 // (diffusion_stereo/src/crossing_out_graph.rs:33-365).  The diffusion batches run on
 // the GPU through DiffusionGraph.  Two modes:
 //   host masks   - vertex and edge masks on the host, as in the reference; the edge mask
-//                  needs O(H*W*4*D^2) bytes, so this is for small images and for
-//                  find_best_labeling;
+//                  needs O(H*W*4*D^2) bytes, so this is for small images;
 //   device       - initialize_with_epsilon + crossing_out run on the GPU (ds_crossing_out),
-//                  only the resulting vertex mask comes back; any image size.
+//                  only the resulting vertex mask comes back; find_best_labeling continues
+//                  on the GPU's masks (ds_find_best_labeling); any image size.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -66,6 +66,7 @@ private:
     void need_host_masks(const char *what) const;
     std::size_t H_ = 0, W_ = 0, D_ = 0;
     bool on_device_ = false;
+    bool device_masks_ = false;  // device mode: the GPU holds masks of some epsilon
     std::vector<std::uint8_t> vertices_, edges_;
 };
 

@@ -283,6 +283,19 @@ bool DiffusionGraph::crossing_out_on_device(double epsilon, std::vector<std::uin
     return not_empty != 0;
 }
 
+Matrix DiffusionGraph::find_best_labeling_on_device(bool &not_empty)
+{
+    push();
+    std::vector<std::uint32_t> flat(H_ * W_);
+    int ok = 0;
+    check(ds_find_best_labeling(h_, 1 << 30, flat.data(), &ok, nullptr));
+    not_empty = ok != 0;
+    Matrix m(H_, std::vector<std::size_t>(W_, 0));
+    for (std::size_t i = 0; i < H_; ++i)
+        for (std::size_t j = 0; j < W_; ++j) m[i][j] = flat[i * W_ + j];
+    return m;
+}
+
 std::vector<double> DiffusionGraph::epsilon_gaps_on_device(bool &largest_repeated)
 {
     push();

@@ -67,6 +67,9 @@ public:
     // (crossing_out_graph.rs:67-183) on the device; vertices[i][j][d] is the resulting
     // vertex mask.  Returns is_not_empty() (:187-193).
     bool crossing_out_on_device(double epsilon, std::vector<std::uint8_t> &vertices, int *passes = nullptr);
+    // find_best_labeling (crossing_out_graph.rs:349-364) on the masks the last
+    // crossing_out_on_device left on the GPU (ds_find_best_labeling).
+    Matrix find_best_labeling_on_device(bool &not_empty);
     // All vertex and edge penalty gaps of the graph (epsilon_search.rs:39-74), computed and
     // sorted on the GPU, exact duplicates removed; largest_repeated: the largest one occurred
     // more than once (ds_epsilon_gaps).

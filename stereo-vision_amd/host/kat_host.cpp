@@ -105,9 +105,9 @@ int main()
         CHECK(c.edge(0, 0, 0, 2, 0) && !c.edge(0, 0, 0, 2, 1));
         CHECK(!c.edge(0, 1, 0, 2, 0) && !c.edge(0, 1, 0, 2, 1) && !c.edge(0, 1, 1, 2, 0) && c.edge(0, 1, 1, 2, 1));
     }
-    {   // crossing_out_graph.rs:643-663 (find_best_labeling -> [0, 0, 1])
+    for (bool on_device : {false, true}) {   // crossing_out_graph.rs:643-663 (find_best_labeling -> [0, 0, 1])
         CrossingOutGraph c = CrossingOutGraph::initialize(
-            DiffusionGraph::initialize(Img{{1, 1, 0}}, Img{{1, 0, 0}}, 3, 1.));
+            DiffusionGraph::initialize(Img{{1, 1, 0}}, Img{{1, 0, 0}}, 3, 1.), on_device);
         DiffusionGraph &g = c.diffusion_graph;
         g.set_potential(0, 0, 2, 0, 0.6);
         g.set_potential(0, 1, 0, 0, -13.7);

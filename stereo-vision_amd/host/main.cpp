@@ -6,7 +6,7 @@
 //                [--epsilon E] [--batch B] [--max-batches M] [--dtype f64|f32]
 //                [--decode crossing|crossing-host|belief|epsilon-search] [--iterations K]
 //                [--tolerance T]
-//                [--schedule red-black|raster] [--quiet]
+//                [--schedule red-black|raster] [--labeling simple|best] [--quiet]
 //
 // --decode crossing (default) is the reference pipeline: diffusion batches on the GPU
 // until the epsilon-consistent sub-graph is non-empty (crossing out on the GPU too), then
@@ -17,6 +17,9 @@
 // --iterations iterations, collects all penalty gaps (small images only; merged within
 // --tolerance), binary-searches the smallest epsilon with a non-empty consistent sub-graph
 // and labels with it.
+// --labeling best takes find_best_labeling (the alternative main.rs:64 keeps commented out)
+// instead of simple_best_labeling: one label per pixel fixed in raster order, with a
+// crossing-out after each choice.
 // --schedule raster sweeps in the reference's sequential order (same results as its
 // CPU implementation up to rounding; one small launch per anti-diagonal, so slower).
 #include <cstdio>
@@ -41,7 +44,7 @@ int main(int argc, char **argv)
     std::size_t max_disparity = 40, batch = 200, max_batches = 1000, iterations = 200;
     double smoothing = 1.2, epsilon = -1., tolerance = 1e-9;
     int dtype = DS_F64;
-    bool crossing = true, host_masks = false, verbose = true, raster = false, search = false;
+    bool crossing = true, host_masks = false, verbose = true, raster = false, search = false, best = false;
     for (int a = 4; a < argc; ++a) {
         const std::string o = argv[a];
         auto need = [&](const char *name) -> const char * {
@@ -77,6 +80,14 @@ int main(int argc, char **argv)
             }
             raster = mode == "raster";
         }
+        else if (o == "--labeling") {
+            const std::string mode = need("--labeling");
+            if (mode != "simple" && mode != "best") {
+                std::fprintf(stderr, "unknown --labeling %s\n", mode.c_str());
+                return 2;
+            }
+            best = mode == "best";
+        }
         else if (o == "--quiet") verbose = false;
         else {
             std::fprintf(stderr, "unknown option %s\n", o.c_str());
@@ -101,12 +112,12 @@ int main(int argc, char **argv)
             const double found = epsilon_search(cog, array);
             std::printf("Smallest consistent epsilon: %.17g\n", found);
             if (!cog.consistent_with_epsilon(found)) throw std::runtime_error("no epsilon in the array is consistent");
-            disparity_map = cog.simple_best_labeling();
+            disparity_map = best ? cog.find_best_labeling() : cog.simple_best_labeling();
         } else if (crossing) {
             CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph), !host_masks);
             cog.diffusion_while_not_consistent(epsilon, batch, max_batches, verbose);
             std::printf("Finding disparity map ...\n");
-            disparity_map = cog.simple_best_labeling();
+            disparity_map = best ? cog.find_best_labeling() : cog.simple_best_labeling();
         } else {
             graph.diffusion(1, iterations, verbose);
             std::printf("Finding disparity map ...\n");

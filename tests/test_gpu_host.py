@@ -85,6 +85,25 @@ def test_cli_epsilon_search(tmp_path, golden_dir):
     assert np.array_equal(m.astype(np.int32), o.simple_best_labeling())
 
 
+def test_cli_find_best_labeling(tmp_path, golden_dir):
+    """--labeling best (find_best_labeling, crossing_out_graph.rs:349-364): the GPU's masks and
+    the host's masks (the reference's own data structures) give the same map from the same
+    potentials.  After whole iterations f_t(d) is zero up to rounding, so the choice between the
+    alive labels of a pixel hangs on the last bits of phi: a run of the oracle's own diffusion is
+    no yardstick here; tests/test_gpu_find_best_labeling.py compares with the oracle on the
+    GPU's potentials instead."""
+    maps = {}
+    for decode in ("crossing", "crossing-host"):
+        out_pgm = tmp_path / ("best_%s.pgm" % decode)
+        run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
+                              os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--decode", decode,
+                              "--labeling", "best", "--epsilon", "2.5", "--batch", "20", "--quiet"],
+                             capture_output=True, text=True, timeout=100, cwd=str(tmp_path))
+        assert run.returncode == 0, run.stdout + run.stderr
+        maps[decode] = pyoracle.pgm_reader(str(out_pgm))[0].astype(np.int32)
+    assert np.array_equal(maps["crossing"], maps["crossing-host"])
+    assert maps["crossing"].max() > 0
+
 def test_cli_belief_decode(tmp_path, golden_dir):
     gold = np.load(os.path.join(golden_dir, "bundled_seq_100.npz"))
     out_pgm = tmp_path / "belief.pgm"
