@@ -32,7 +32,7 @@ def _graphs(H, W, D, dtype, seed, iters=0):
 
 @pytest.mark.parametrize("H,W,D,dtype", [(5, 5, 40, "f64"), (6, 9, 5, "f64"), (4, 11, 8, "f32"),
                                          (3, 2, 3, "f64"), (1, 7, 4, "f64"), (7, 1, 4, "f32"),
-                                         (5, 13, 17, "f64")])
+                                         (5, 13, 17, "f64"), (2, 5, 256, "f32"), (3, 4, 130, "f64")])
 def test_gaps_match_oracle(H, W, D, dtype):
     g, o = _graphs(H, W, D, dtype, seed=H * 100 + W)
     got = g.epsilon_gaps()

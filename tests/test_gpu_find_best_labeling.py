@@ -29,7 +29,8 @@ def _run(H, W, D, dtype, iters, eps, seed):
 @pytest.mark.parametrize("H,W,D,dtype,iters,eps", [(5, 7, 6, "f64", 30, 3.0), (6, 9, 12, "f64", 10, 8.0),
                                                   (4, 12, 5, "f32", 20, 2.0), (9, 9, 40, "f64", 5, 20.0),
                                                   (3, 5, 4, "f64", 0, 1e9), (1, 9, 6, "f64", 15, 4.0),
-                                                  (8, 1, 3, "f64", 15, 4.0)])
+                                                  (8, 1, 3, "f64", 15, 4.0), (3, 6, 256, "f32", 4, 30.0),
+                                                  (4, 5, 100, "f64", 6, 25.0)])
 def test_same_map_as_the_oracle(H, W, D, dtype, iters, eps):
     g, o, first = _run(H, W, D, dtype, iters, eps, seed=H * 31 + W)
     assert first["not_empty"]
