@@ -73,10 +73,12 @@ def diffusion_while_not_consistent(runner, epsilon, batch_size, max_batches=1000
 
 
 def run(left, right, max_disparity=40, smoothing=1.2, epsilon=None, batch=200, max_batches=1000,
-        dtype="f64", log=None):
+        dtype="f64", log=None, labeling="simple"):
     """The pipeline on already loaded images.  Uses the default process group if one is
     initialised (one band per rank), else a single band.  Returns (disparity map [H][W] on
-    rank 0, None elsewhere; iterations done)."""
+    rank 0, None elsewhere; iterations done).  labeling: "simple" = simple_best_labeling
+    (crossing_out_graph.rs:318-327, what the reference's main uses), "best" = find_best_labeling
+    (:349-364; sequential over the whole image, so one band only)."""
     import torch
     import torch.distributed as dist
     from . import bands, diffstereo
@@ -85,6 +87,10 @@ def run(left, right, max_disparity=40, smoothing=1.2, epsilon=None, batch=200, m
         raise ValueError("intensities must fit 8 bits")
     epsilon = 1.0 / (10.0 * W * H) if epsilon is None else epsilon
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if labeling not in ("simple", "best"):
+        raise ValueError("labeling must be 'simple' or 'best'")
+    if labeling == "best" and multi:
+        raise ValueError("find_best_labeling walks the whole image pixel by pixel: run it as one process")
     rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
     rb, re = bands.partition_rows(H, world)[rank]
     graph = diffstereo.DiffusionGraph(left.astype(np.uint8), right.astype(np.uint8), max_disparity, smoothing,
@@ -95,6 +101,11 @@ def run(left, right, max_disparity=40, smoothing=1.2, epsilon=None, batch=200, m
         iters, result = diffusion_while_not_consistent(runner, epsilon, batch, max_batches,
                                                        log if rank == 0 else None)
         labels = result["labels"]
+        if labeling == "best":
+            best = graph.find_best_labeling()   # continues on the masks the crossing-out left
+            if not best["not_empty"]:
+                raise RuntimeError("Graph is empty")
+            labels = best["labels"]
         if not multi:
             return labels, iters
         parts = [None] * world if rank == 0 else None
@@ -116,6 +127,7 @@ def main(argv=None):
     ap.add_argument("--max-batches", type=int, default=1000)
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl")
+    ap.add_argument("--labeling", choices=("simple", "best"), default="simple")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args(argv)
     import torch
@@ -133,7 +145,7 @@ def main(argv=None):
             raise ValueError("left and right images differ in size")
         log = None if a.quiet else (lambda s: print(s, flush=True))
         labels, _ = run(left, right, a.max_disparity, a.smoothing, a.epsilon, a.batch, a.max_batches,
-                        a.dtype, log)
+                        a.dtype, log, a.labeling)
         if rank == 0:
             print("Disparity map is consistent: %s" % ("true" if check_disparity_map(labels) else "false"))
             pgm_writer(labels, a.out, a.max_disparity)

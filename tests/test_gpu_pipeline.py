@@ -34,6 +34,25 @@ def test_single_process(golden_dir):
     assert abs(energy - float(gold["energy_cb"])) <= 1e-9 * abs(float(gold["energy_cb"]))
 
 
+def test_find_best_labeling_matches_the_cli(tmp_path, golden_dir):
+    """labeling="best" (crossing_out_graph.rs:349-364) in the Python pipeline and in the C++ CLI:
+    the same library calls in the same order, so the same potentials and the same choices."""
+    left, _ = pipeline.pgm_reader(golden_dir + "/left.pgm")
+    right, _ = pipeline.pgm_reader(golden_dir + "/right.pgm")
+    labels, iters = pipeline.run(left, right, epsilon=2.5, batch=20, labeling="best")
+    assert iters == 20 and labels.max() > 0
+    out_pgm = tmp_path / "best.pgm"
+    cli = os.path.join(PKG_DIR, "host", "stereovision")
+    run = subprocess.run([cli, golden_dir + "/left.pgm", golden_dir + "/right.pgm", str(out_pgm), "--labeling", "best",
+                          "--epsilon", "2.5", "--batch", "20", "--quiet"],
+                         capture_output=True, text=True, timeout=100, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stdout + run.stderr
+    m, _ = pipeline.pgm_reader(str(out_pgm))
+    assert np.array_equal(labels.astype(np.int64), m.astype(np.int64))
+    with pytest.raises(ValueError):
+        pipeline.run(left, right, labeling="greedy")
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
