@@ -35,6 +35,73 @@ struct Lds {
 };
 
 using V = ds::V4<float>;
+typedef float F2 __attribute__((ext_vector_type(2)));
+
+// ds::messages_fused<64> with its additions two labels at a time (v_pk_add_f32): the same
+// IEEE additions, fewer instructions.  -DPACKED_ADDS selects it: a measurement of what trimming
+// vector instructions is worth once the kernel is no longer bound by HBM.
+__device__ __forceinline__ void messages_packed(const V psi[4], const float lam[4], float lam1, int lane, V M[4])
+{
+    using R = ds::Real<float>;
+    const float inf = R::inf();
+    const F2 lam_lo = {lam[0], lam[1]}, lam_hi = {lam[2], lam[3]};
+    float p[3][4], sfx[3][4];
+    const int pslot[3] = {1, 2, 3}, sslot[3] = {0, 1, 3};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const V &x = psi[pslot[t]];
+        const F2 a_lo = F2{x.v[0], x.v[1]} - lam_lo, a_hi = F2{x.v[2], x.v[3]} - lam_hi;
+        p[t][0] = a_lo.x;
+        p[t][1] = R::min(p[t][0], a_lo.y);
+        p[t][2] = R::min(p[t][1], a_hi.x);
+        p[t][3] = R::min(p[t][2], a_hi.y);
+        const V &y = psi[sslot[t]];
+        const F2 b_lo = F2{y.v[0], y.v[1]} + lam_lo, b_hi = F2{y.v[2], y.v[3]} + lam_hi;
+        sfx[t][3] = b_hi.y;
+        sfx[t][2] = R::min(sfx[t][3], b_hi.x);
+        sfx[t][1] = R::min(sfx[t][2], b_lo.y);
+        sfx[t][0] = R::min(sfx[t][1], b_lo.x);
+    }
+    float up[3], down[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        up[t] = ds::dpp<ds::DPP_WAVE_SHR1>(inf, p[t][3]);
+        down[t] = ds::dpp<ds::DPP_WAVE_SHL1>(inf, sfx[t][0]);
+    }
+    ds::fused_scans6<64>(up, down);
+    const int row = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float t1 = ds::readlane(down[t], 16), t2 = ds::readlane(down[t], 32), t3 = ds::readlane(down[t], 48);
+        const float c23 = R::min(t2, t3), c123 = R::min(t1, c23);
+        const float add = row == 0 ? c123 : row == 1 ? c23 : row == 2 ? t3 : inf;
+        down[t] = R::min(down[t], add);
+    }
+    float fwd[3][4], bwd[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const F2 f_lo = F2{R::min(p[t][0], up[t]), R::min(p[t][1], up[t])} + lam_lo;
+        const F2 f_hi = F2{R::min(p[t][2], up[t]), R::min(p[t][3], up[t])} + lam_hi;
+        const F2 b_lo = F2{R::min(sfx[t][0], down[t]), R::min(sfx[t][1], down[t])} - lam_lo;
+        const F2 b_hi = F2{R::min(sfx[t][2], down[t]), R::min(sfx[t][3], down[t])} - lam_hi;
+        fwd[t][0] = f_lo.x; fwd[t][1] = f_lo.y; fwd[t][2] = f_hi.x; fwd[t][3] = f_hi.y;
+        bwd[t][0] = b_lo.x; bwd[t][1] = b_lo.y; bwd[t][2] = b_hi.x; bwd[t][3] = b_hi.y;
+    }
+    const float prev = ds::dpp<ds::DPP_WAVE_SHR1>(inf, psi[0].v[3]);
+    const float next = ds::dpp<ds::DPP_WAVE_SHL1>(inf, psi[2].v[0]);
+    const F2 l1 = {lam1, lam1};
+    const F2 left_lo = l1 + F2{prev, psi[0].v[0]}, left_hi = l1 + F2{psi[0].v[1], psi[0].v[2]};
+    const F2 right_lo = l1 + F2{psi[2].v[1], psi[2].v[2]}, right_hi = l1 + F2{psi[2].v[3], next};
+    const float left[4] = {left_lo.x, left_lo.y, left_hi.x, left_hi.y};
+    const float right[4] = {right_lo.x, right_lo.y, right_hi.x, right_hi.y};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        M[0].v[k] = R::min(bwd[0][k], left[k]);
+        M[1].v[k] = R::min(fwd[0][k], bwd[1][k]);
+        M[2].v[k] = R::min(fwd[1][k], right[k]);
+        M[3].v[k] = R::min(fwd[2][k], bwd[2][k]);
+    }
+}
 
 __global__ __launch_bounds__(64 * FW) void fused2_kernel(ds::Geometry g, const float *__restrict__ phi,
                                                          float *__restrict__ phi_new, long long new_plane_stride,
@@ -58,7 +125,11 @@ __global__ __launch_bounds__(64 * FW) void fused2_kernel(ds::Geometry g, const f
     auto update = [&](const V psi[4], uint32_t cost_word, V out[4]) {
         V M[4];
         const V qc = unpack_cost<float>(cost_word);
+#ifdef PACKED_ADDS
+        messages_packed(psi, lam, lambda, lane, M);
+#else
         messages_fused<64>(psi, lam, lambda, lane, lane, M);
+#endif
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float avg = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * 0.25f;
