@@ -71,10 +71,13 @@ def _worker(rank, world, port, dtype, D, H, W, out):
 
 
 @pytest.mark.parametrize("world,dtype,D,H,W", [(2, "f32", 24, 13, 45), (3, "f64", 24, 13, 45), (2, "f32", 256, 29, 75),
-                                               (3, "f64", 140, 29, 75), (2, "f64", 64, 17, 130), (3, "f32", 100, 40, 33)])
+                                               (3, "f64", 140, 29, 75), (2, "f64", 64, 17, 130), (3, "f32", 100, 40, 33),
+                                               (3, "f32", 64, 23, 70), (4, "f64", 40, 33, 52)])
 def test_two_ranks_one_gpu(world, dtype, D, H, W):
     """Bands of 4-7 rows (H = 13) fall back to half-sweeps per colour; bands of 9-15 rows
-    (H = 29) iterate with the fused kernel in their interior (bands.BandRunner._fused_iteration)."""
+    (H = 29) iterate with the fused kernel in their interior (bands.BandRunner._fused_iteration).
+    H = 23 over three ranks gives bands of 8, 8 and 7 rows: two ranks on the fused protocol next to
+    one on half-sweeps (the messages that travel are the same); H = 33 over four: 9, 8, 8, 8."""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     out = mgr.dict()
