@@ -249,6 +249,252 @@ __global__ __launch_bounds__(64 * FW) void fused2_kernel(ds::Geometry g, const f
     }
 }
 
+// ---- the same with the image's borders: every stage has the masked path of the library's kernel
+// (pixels without four neighbours, labels d > j, strips that hang over the image's edges), so the
+// launch covers the whole image.  Strips start two columns left of their first output column.
+__global__ __launch_bounds__(64 * FW) void fused2_general_kernel(ds::Geometry g, const float *__restrict__ phi,
+                                                                 float *__restrict__ phi_new, long long new_plane_stride,
+                                                                 const uint8_t *__restrict__ cost, float lambda,
+                                                                 int row_begin, int row_end, int rows_per_seg)
+{
+    using namespace ds;
+    __shared__ Lds lds;
+    const float inf = __builtin_huge_valf();
+    const int lane = threadIdx.x & 63, kp = threadIdx.x >> 6;
+    const int d0 = 4 * lane;
+    float lam[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lam[c] = lambda * (float)(d0 + c);
+    const int c0 = (int)blockIdx.x * FC - 2;    // first output column is c0 + 2
+    const int a = c0 - 1 + 2 * kp;
+    const int r0 = row_begin + blockIdx.y * rows_per_seg;
+    const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
+    const uint8_t *cost_red = cost, *cost_black = cost + g.cost_colour_stride;
+    const bool cols_interior = g.D == DL && c0 - 1 >= g.D && c0 + 32 < g.W;
+    const V none = splat(inf);
+    auto clampk = [&](int k) { return k < 0 ? 0 : k > FW - 1 ? FW - 1 : k; };
+    auto rows_interior = [&](int r) { return r >= 1 && r + 1 < g.H; };
+
+    // out[n] of a pixel from its four incoming rows and its cost word; masked form for px
+    auto update_fast = [&](const V psi[4], uint32_t cost_word, V out[4]) {
+        V M[4];
+        const V qc = unpack_cost<float>(cost_word);
+        messages_fused<64>(psi, lam, lambda, lane, lane, M);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float avg = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * 0.25f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) out[n].v[c] = avg - M[n].v[c];
+        }
+    };
+    auto update_masked = [&](const Pixel &px, const V psi[4], const V &qc, V out[4]) {
+        V M[4];
+        messages_fused<64>(psi, lam, lambda, lane, lane, M);
+        const int K = px.j < g.D - 1 ? px.j : g.D - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc += px.has[n] ? M[n].v[c] : 0.f;
+            const float avg = divide_by_neighbours(qc.v[c] + acc, px.nn);
+            const bool valid = px.active && d0 + c <= K;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) out[n].v[c] = (valid && px.has[n]) ? avg - M[n].v[c] : inf;
+        }
+    };
+    auto red_pixel = [&](int r, bool mine) {
+        const int p = r & 1;
+        const int j = p ? a : a + 1;
+        Pixel px = locate(g, r, p, j >> 1, d0);
+        px.active = px.active && mine && j >= 0;
+        return px;
+    };
+    auto black_pixel = [&](int i, bool mine) {
+        const int p = i & 1;
+        const int j = p ? a + 1 : a;
+        Pixel px = locate(g, i, (i + 1) & 1, j >> 1, d0);
+        px.active = px.active && mine && j >= 0;
+        return px;
+    };
+
+    V pre_psi[4];
+    uint32_t pre_cost = 0;
+    auto fetch = [&](int r) {
+        if (r < 0 || r >= g.H) return;
+        const int p = r & 1;
+        const int j = p ? a : a + 1;
+        const int jc = j >> 1, il = r - g.row0 + 1;
+        if (cols_interior && rows_interior(r)) {
+            const long long own = (long long)il * g.row_stride + (long long)jc * g.Dpad + d0;
+            const long long nb[4] = {own + (long long)(p - 1) * g.Dpad, own - g.row_stride,
+                                     own + (long long)p * g.Dpad, own + g.row_stride};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) pre_psi[n] = ld4_nt(phi + g.plane_off[1][n ^ 2] + nb[n]);
+            pre_cost = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                cost_red + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d0));
+        } else {
+            const Pixel px = red_pixel(r, true);
+            load_psi(g, phi, 1, px, pre_psi);
+            pre_cost = (px.active && px.d0 <= px.j) ? *reinterpret_cast<const uint32_t *>(cost_red + px.cost) : 0u;
+        }
+    };
+    V a_down_prev = none, a_down_cur = none, a_side_cur = none, a_down_next, a_side_next, a_up_next;
+    V b_down_prev = none, b_down_cur = none, b_side_cur = none, b_down_next, b_side_next, b_up_next;
+    V c_down_prev = none, c_down_cur = none, c_side_cur = none, c_down_next, c_side_next, c_up_next;
+
+    auto stage_a = [&](int r) {  // red(r), first iteration, from memory
+        a_down_next = a_side_next = a_up_next = none;
+        if (r < 0 || r >= g.H) return;
+        const int p = r & 1;
+        V psi[4], out[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) psi[n] = pre_psi[n];
+        if (cols_interior && rows_interior(r)) update_fast(psi, pre_cost, out);
+        else update_masked(red_pixel(r, true), psi, unpack_cost<float>(pre_cost), out);
+        store4(&lds.ring1[p][kp][d0], pick(p != 0, out[0], out[2]));
+        a_side_next = pick(p != 0, out[2], out[0]);
+        a_up_next = out[1];
+        a_down_next = out[3];
+    };
+    // a black pixel's four incoming rows: own pair's red pixel of the same row, the neighbouring
+    // pair's (through LDS), own pair's red pixels of the rows above and below
+    auto black_inputs = [&](int i, const Pixel &px, bool fast, const float (*ring)[FW][DL], const V &side_cur,
+                            const V &down_prev, const V &up_next, V psi[4]) {
+        const int p = i & 1;
+        const int nbr = clampk(p ? kp + 1 : kp - 1);
+        if (fast) {
+            const V across = load4(&ring[p][nbr][d0]);
+            psi[0] = pick(p != 0, side_cur, across);
+            psi[1] = down_prev;
+            psi[2] = pick(p != 0, across, side_cur);
+            psi[3] = up_next;
+        } else {
+            const bool has_across = px.active && (p ? px.has[2] : px.has[0]);
+            const bool has_own = px.active && (p ? px.has[0] : px.has[2]);
+            V across = none;
+            if (has_across) across = load4(&ring[p][nbr][d0]);
+            const V own_side = pick(has_own, side_cur, none);
+            psi[0] = pick(p != 0, own_side, across);
+            psi[1] = pick(px.active && px.has[1], down_prev, none);
+            psi[2] = pick(p != 0, across, own_side);
+            psi[3] = pick(px.active && px.has[3], up_next, none);
+        }
+    };
+    auto stage_b = [&](int i) {  // black(i), first iteration: stays on chip
+        b_down_next = b_side_next = b_up_next = none;
+        if (i < 0 || i >= g.H) return;
+        const int p = i & 1;
+        const bool mine = p ? kp <= FW - 2 : kp >= 1;
+        const bool fast = cols_interior && rows_interior(i);
+        const Pixel px = black_pixel(i, mine);
+        V psi[4], out[4];
+        black_inputs(i, px, fast, lds.ring1, a_side_cur, a_down_prev, a_up_next, psi);
+        if (fast) {
+            const int j = p ? a + 1 : a;
+            update_fast(psi, __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                                 cost_black + ((long long)(i - g.row0) * g.Wh + (j >> 1)) * g.Dpad + d0)), out);
+        } else {
+            update_masked(px, psi, load_cost<float>(cost_black, px), out);
+        }
+        store4(&lds.ring2[p][kp][d0], pick(p != 0, out[2], out[0]));
+        b_side_next = pick(p != 0, out[0], out[2]);
+        b_up_next = out[1];
+        b_down_next = out[3];
+    };
+    auto stage_c = [&](int r) {  // red(r), second iteration, from the first iteration's black pixels on chip
+        c_down_next = c_side_next = c_up_next = none;
+        if (r < 0 || r >= g.H) return;
+        const int p = r & 1;
+        const bool fast = cols_interior && rows_interior(r);
+        const Pixel px = red_pixel(r, kp >= 1 && kp <= FW - 2);
+        const int nbr = clampk(p ? kp - 1 : kp + 1);
+        V psi[4], out[4];
+        if (fast) {
+            const V across = load4(&lds.ring2[p][nbr][d0]);
+            psi[0] = pick(p != 0, across, b_side_cur);
+            psi[1] = b_down_prev;
+            psi[2] = pick(p != 0, b_side_cur, across);
+            psi[3] = b_up_next;
+            const int j = p ? a : a + 1;
+            update_fast(psi, __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                                 cost_red + ((long long)(r - g.row0) * g.Wh + (j >> 1)) * g.Dpad + d0)), out);
+        } else {
+            // odd row: red at a, left neighbour = previous pair's black, right = own pair's; even: mirrored
+            const bool has_across = px.active && (p ? px.has[0] : px.has[2]);
+            const bool has_own = px.active && (p ? px.has[2] : px.has[0]);
+            V across = none;
+            if (has_across) across = load4(&lds.ring2[p][nbr][d0]);
+            const V own_side = pick(has_own, b_side_cur, none);
+            psi[0] = pick(p != 0, across, own_side);
+            psi[1] = pick(px.active && px.has[1], b_down_prev, none);
+            psi[2] = pick(p != 0, own_side, across);
+            psi[3] = pick(px.active && px.has[3], b_up_next, none);
+            update_masked(px, psi, load_cost<float>(cost_red, px), out);
+        }
+        store4(&lds.ring3[p][kp][d0], pick(p != 0, out[0], out[2]));
+        c_side_next = pick(p != 0, out[2], out[0]);
+        c_up_next = out[1];
+        c_down_next = out[3];
+    };
+    auto stage_d = [&](int i) {  // black(i), second iteration: to memory
+        const int p = i & 1;
+        const bool mine = p ? (kp >= 1 && kp <= OUT_PAIRS) : (kp >= 2 && kp <= OUT_PAIRS + 1);
+        const bool fast = cols_interior && rows_interior(i);
+        const Pixel px = black_pixel(i, mine);
+        V psi[4], out[4];
+        black_inputs(i, px, fast, lds.ring3, c_side_cur, c_down_prev, c_up_next, psi);
+        if (fast) {
+            const int j = p ? a + 1 : a;
+            update_fast(psi, __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(
+                                 cost_black + ((long long)(i - g.row0) * g.Wh + (j >> 1)) * g.Dpad + d0)), out);
+            if (mine) {
+                const long long own = (long long)(i - g.row0 + 1) * g.row_stride + (long long)(j >> 1) * g.Dpad + d0;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) st4_nt(phi_new + n * new_plane_stride + own, out[n]);
+            }
+        } else {
+            update_masked(px, psi, load_cost<float>(cost_black, px), out);
+            const int K = px.j < g.D - 1 ? px.j : g.D - 1;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (px.active && px.has[n] && d0 <= K) store4(phi_new + n * new_plane_stride + px.own, out[n]);
+        }
+    };
+    auto rotate = [&]() {
+        a_down_prev = a_down_cur; a_down_cur = a_down_next; a_side_cur = a_side_next;
+        b_down_prev = b_down_cur; b_down_cur = b_down_next; b_side_cur = b_side_next;
+        c_down_prev = c_down_cur; c_down_cur = c_down_next; c_side_cur = c_side_next;
+    };
+
+    fetch(r0 - 3);
+    stage_a(r0 - 3);
+    rotate();
+    fetch(r0 - 2);
+    stage_a(r0 - 2);
+    rotate();
+    fetch(r0 - 1);
+    __syncthreads();
+    for (int i = r0 - 2; i < r1 + 2; ++i) {
+        stage_a(i + 1);
+        if (i + 2 < r1 + 3) fetch(i + 2);
+        stage_b(i);
+        if (i - 1 >= r0 - 1) stage_c(i - 1);
+        if (i - 2 >= r0) stage_d(i - 2);
+        rotate();
+        __syncthreads();
+    }
+}
+
+// finite entries (the labels the reference uses) get random values; +inf entries stay
+__global__ void perturb_kernel(float *p, long long n, unsigned seed)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        if (p[i] < __builtin_huge_valf()) p[i] = (float)(x & 0xffff) * (1.0f / 1024.0f) - 32.0f;
+    }
+}
+
 __global__ void fill_kernel(float *p, long long n, unsigned seed)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -376,5 +622,63 @@ int main(int argc, char **argv)
                 ms1, ms1 * frac, 100 * frac);
     std::printf("two-in-one / two launches on the same pixels: %.3f   mismatching dwords in the interior: %llu\n",
                 ms2 / (ms1 * frac), h_bad);
+
+    // ---- second part: the kernel with the borders' masked paths, over the whole image
+    {
+        auto init_like_phi = [&](float *buf) {  // 0 on the reference's labels, +inf elsewhere, as ds_create leaves phi
+            ds::Geometry t = g;
+            for (int n = 0; n < 4; ++n) t.plane_off[1][n] = (buf - phi) + n * plane;  // colour-0 planes: phi's own, unused here
+            hipLaunchKernelGGL(ds::init_phi_kernel<float>, dim3(8192), dim3(ds::kBlock), 0, 0, t, phi);
+        };
+        hipLaunchKernelGGL(ds::init_phi_kernel<float>, dim3(8192), dim3(ds::kBlock), 0, 0, g, phi);
+        hipLaunchKernelGGL(perturb_kernel, dim3(8192), dim3(256), 0, 0, phi, 8 * plane, 777u);
+        init_like_phi(out2);
+        init_like_phi(ref1);
+        init_like_phi(ref2);
+        CK(hipDeviceSynchronize());
+        const int strips_g = (g.W + FC - 1) / FC + 1, nseg_g = (g.H + rows_per_seg - 1) / rows_per_seg;
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            float ms = 0;
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(fused2_general_kernel, dim3(strips_g, nseg_g), dim3(64 * FW), 0, 0, g, phi, out2, plane, cost,
+                               lambda, 0, g.H, rows_per_seg);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best;
+        }
+        const int strips_all = (g.W + 29) / 30;
+        const int nseg = 34, rps = (g.H + nseg - 1) / nseg;
+        ds::FusedPlanes np1, np2;
+        ds::Geometry g2 = g;
+        for (int n = 0; n < 4; ++n) {
+            np1.out_off[n] = (ref1 - phi) + n * plane;
+            np2.out_off[n] = (ref2 - phi) + n * plane;
+            g2.plane_off[1][n] = (ref1 - phi) + n * plane;
+        }
+        float lib = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            float ms = 0;
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 64, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
+                               dim3(64 * 16), 0, 0, g, phi, np1, cost, lambda, 0, g.H, rps);
+            hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 64, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
+                               dim3(64 * 16), 0, 0, g2, phi, np2, cost, lambda, 0, g.H, rps);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            lib = ms < lib ? ms : lib;
+        }
+        CK(hipMemset(bad, 0, 8));
+        hipLaunchKernelGGL(compare_kernel, dim3(4096), dim3(256), 0, 0, g, out2, ref2, plane, 0, g.H, 0, g.W, bad);
+        unsigned long long whole_bad = 0;
+        CK(hipMemcpy(&whole_bad, bad, 8, hipMemcpyDeviceToHost));
+        std::printf("with borders, whole image: two iterations in one launch %.3f ms, two launches of the library kernel %.3f ms "
+                    "(x%.3f); mismatching dwords: %llu\n", best, lib, best / lib, whole_bad);
+        h_bad += whole_bad;
+    }
     return h_bad ? 1 : 0;
 }
