@@ -710,6 +710,35 @@ int main(int argc, char **argv)
             CK(hipEventElapsedTime(&ms, e0, e1));
             best_split = ms < best_split ? ms : best_split;
         }
+        // the same two launches side by side on two streams (the masked one first: its blocks are the slow ones)
+        {
+            hipStream_t s1, s2;
+            CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+            CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            hipEvent_t done2;
+            CK(hipEventCreate(&done2));
+            CK(hipDeviceSynchronize());
+            float best_par = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                float ms = 0;
+                CK(hipEventRecord(e0, s1));
+                CK(hipStreamWaitEvent(s2, e0, 0));
+                hipLaunchKernelGGL(fused2_general_kernel, dim3(strips_g, nseg_g), dim3(64 * FW), 0, s2, g, phi, out2, plane,
+                                   cost, lambda, 0, g.H, rows_per_seg, true);
+                hipLaunchKernelGGL(fused2_kernel, dim3(strips_g, nseg_g), dim3(64 * FW), 0, s1, g, phi, out2, plane, cost,
+                                   lambda, -2, 0, rows_per_seg, g.H, true);
+                CK(hipEventRecord(done2, s2));
+                CK(hipStreamWaitEvent(s1, done2, 0));
+                CK(hipEventRecord(e1, s1));
+                CK(hipEventSynchronize(e1));
+                CK(hipGetLastError());
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best_par = ms < best_par ? ms : best_par;
+            }
+            std::printf("with borders, the two kernels side by side on two streams: %.3f ms (x%.3f)\n", best_par, best_par / lib);
+            CK(hipStreamDestroy(s1));
+            CK(hipStreamDestroy(s2));
+        }
         CK(hipMemset(bad, 0, 8));
         hipLaunchKernelGGL(compare_kernel, dim3(4096), dim3(256), 0, 0, g, out2, ref2, plane, 0, g.H, 0, g.W, bad);
         unsigned long long split_bad = 0;
