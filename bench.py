@@ -75,6 +75,16 @@ def cpu_baseline(left, right, D, lam, budget_s=12.0):
     out = {"value": pl * iters / dt / 1e9, "unit": "G pixel*label*iters/s", "cores": 1, "kind": "port",
            "sample": "C restatement of diffusion_act (raster order, O(D^2), f64), %d iteration(s) on the "
                      "%dx%d top-left crop of the same synthetic pair, D=%d, %.1f s" % (iters, W, H, D, dt)}
+    # the same restatement at the reference's own working scale (main.rs:38-47: images of about
+    # 400x400, 40 disparities), where its O(D^2) cost per pixel is 40x smaller than at D = 256
+    rs = min(left.shape[0], 200), min(left.shape[1], 400)   # half its rows: the sample stays a few seconds
+    g = pyoracle.OracleGraph(left[:rs[0], :rs[1]], right[:rs[0], :rs[1]], 40, lam)
+    t0 = time.perf_counter()
+    g.diffusion_act()
+    dt_rs = time.perf_counter() - t0
+    out["reference_scale"] = {"value": valid_pairs(rs[0], rs[1], 40) / dt_rs / 1e9, "cores": 1,
+                              "sample": "the same restatement, 1 iteration on the %dx%d top-left crop, D=40, %.1f s"
+                                        % (rs[1], rs[0], dt_rs)}
     # the O(D) OpenMP port of the checkerboard sweep, all host threads OpenMP gives us
     Hf = min(left.shape[0], 96)
     f = pyoracle.FastOracle(left[:Hf], right[:Hf], D, lam, dtype="f32")
