@@ -19,6 +19,8 @@ a bounded crop of the same workload).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -98,6 +100,40 @@ def cpu_baseline(left, right, D, lam, budget_s=12.0):
     return out
 
 
+def spawn_ranks(n):
+    """Run this script as n child processes (ranks 0..n-1, one per GPU) with the environment
+    torch.distributed.run would give them; returns the first non-zero exit status, else 0."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    status = 0
+    try:
+        pending = list(children)
+        while pending and status == 0:
+            time.sleep(0.2)
+            for child in list(pending):
+                rc = child.poll()
+                if rc is not None:
+                    pending.remove(child)
+                    status = status or rc
+    finally:
+        for child in children:  # a rank that failed must not leave its peers waiting for it
+            if child.poll() is None:
+                child.terminate()
+        for child in children:
+            try:
+                child.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                child.kill()
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +146,10 @@ def main():
                          "(what one GPU of a larger job sweeps; a timing, not a result)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly (not by torch.distributed.run): start one rank per GPU ourselves.
+        # This process has made no GPU call yet and makes none: it only waits for its children.
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

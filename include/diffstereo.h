@@ -111,7 +111,12 @@ int ds_iterate(ds_handle *h, int n_iters);
  *                               the produced planes current.
  * After the last iteration ds_finish_iterations brings the first colour's planes up to date
  * (they are not written by ds_iterate_rows).  ds_fused_rows returns an empty range on handles
- * created with DS_FUSED=off.  The result is bit-identical to half-sweeps with ds_sweep. */
+ * created with DS_FUSED=off.  The result is bit-identical to half-sweeps with ds_sweep.
+ * ds_iterate_rows takes exactly the range ds_fused_rows reports.  Between ds_iterate_rows and
+ * ds_finish_iterations the first colour's planes are out of date: the entry points that read phi
+ * (ds_energy, ds_labels, ds_get_phi*, ds_set_phi*, ds_checksum, ds_co_begin, ds_epsilon_gaps,
+ * ds_iterate_raster) return DS_ERR_STATE until ds_finish_iterations has run, which is a no-op
+ * when nothing is pending. */
 int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end);
 /* ds_sweep (next = 0) or ds_sweep_next (next = 1, colour 1 only) over two disjoint row ranges in
  * one launch: a band's first and last rows. */

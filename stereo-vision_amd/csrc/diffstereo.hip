@@ -48,6 +48,7 @@ struct ds_handle {
     void *phi = nullptr;
     void *phi_b = nullptr;        // group B when allocated apart, else NULL
     int fused_waves = 0;          // wavefronts per block of the fused kernel; 0 = not available
+    bool fused_pending = false;   // fused launches since the first colour's planes were last current
     int cu_count = 256;
     long long alt_off[4] = {0, 0, 0, 0};
     std::vector<int> prof_kind;   // per timed launch: 0 = half-sweep, 1 = fused iteration
@@ -147,6 +148,15 @@ int use_device(ds_handle *h)
     return DS_OK;
 }
 
+// The readers of phi need both colours' planes current.
+int need_current(ds_handle *h, const char *who)
+{
+    if (h->fused_pending)
+        return fail(h, DS_ERR_STATE, std::string(who) + ": the first colour's planes are out of date after "
+                                     "ds_iterate_rows; call ds_finish_iterations first");
+    return DS_OK;
+}
+
 void release(ds_handle *h)
 {
     if (!h) return;
@@ -233,8 +243,10 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
     ds::Geometry &g = h->g;
     int safe_begin = 0, safe_end = 0;
     fused_safe_rows(h, &safe_begin, &safe_end);
-    if (!h->fused_waves || row_begin < safe_begin || row_end > safe_end)
-        return fail(h, DS_ERR_ARG, "fused iteration outside the rows this handle can update in one kernel");
+    // Exactly the safe rows: the launch makes the other set of colour-1 planes current, so rows
+    // it leaves out would silently fall back to what that set held two iterations ago.
+    if (!h->fused_waves || row_begin != safe_begin || row_end != safe_end)
+        return fail(h, DS_ERR_ARG, "a fused iteration must cover exactly the rows ds_fused_rows reports");
     const bool timed = h->prof && h->prof_n < h->prof_cap;
     if (timed) {
         HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
@@ -287,6 +299,7 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
         ++h->prof_n;
     }
     for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
+    h->fused_pending = true;
     return DS_OK;
 }
 
@@ -295,9 +308,12 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
 // hold right after a fused launch.
 int materialise_first_colour(ds_handle *h, int row_begin, int row_end)
 {
+    if (!h->fused_pending) return DS_OK;  // nothing to bring up to date (and the alternate planes hold no input)
     ds::Geometry before = h->g;
     for (int s = 0; s < 4; ++s) before.plane_off[1][s] = h->alt_off[s];
-    return launch_sweep(h, 0, row_begin, row_end, &before);
+    int rc = launch_sweep(h, 0, row_begin, row_end, &before);
+    if (rc == DS_OK) h->fused_pending = false;
+    return rc;
 }
 
 int build_cost(ds_handle *h)
@@ -339,6 +355,7 @@ int init_phi(ds_handle *h)
                                h->stream, alt, static_cast<float *>(h->phi));
         HIPCHK(h, hipGetLastError());
     }
+    h->fused_pending = false;
     return DS_OK;
 }
 
@@ -416,9 +433,17 @@ int place_phi(ds_handle *h)
                     std::string("hipMalloc(phi group A): ") + hipGetErrorString(e));
     double best = 0.0;
     int rc = DS_OK, since_gain = 0;
+    // The spacers are transient, but other tenants of the GPU see them: never hold more than
+    // half of what was free when the search began.
+    size_t spacer_budget = 0;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) spacer_budget = free_b / 2;
+    }
     for (int attempt = 0; attempt < max_tries; ++attempt) {
         if (attempt > 0) {  // push the next candidate further away
             size_t free_b = 0, total_b = 0;
+            if ((spacers.size() + 1) * spacer_bytes > spacer_budget) break;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < spacer_bytes + group_bytes + (4ull << 30)) break;
             void *sp = nullptr;
             if (hipMalloc(&sp, spacer_bytes) != hipSuccess) {
@@ -562,7 +587,7 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     CREATE_HIPCHK(hipMalloc(&h->cost_lm, (size_t)D * g.Hb * W + 4));
     CREATE_HIPCHK(hipMalloc(&h->cost_px, (size_t)(2 * g.cost_colour_stride)));
     // phi is allocated last, by place_phi(), once the kernels it probes with can run
-    h->part_n = 2ll * h->grid_x * g.Hb * (ds::kBlock / 64);
+    h->part_n = 2ll * h->grid_x * g.Hb;  // one partial per block of the two energy launches
     // + kReduceBlocks entries behind the partials for the first reduction stage's results
     CREATE_HIPCHK(hipMalloc(&h->part_sum, (size_t)(h->part_n + kReduceBlocks) * sizeof(double)));
     CREATE_HIPCHK(hipMalloc(&h->part_max, (size_t)(h->part_n + kReduceBlocks) * sizeof(double)));
@@ -640,7 +665,8 @@ int phi_rows(ds_handle *h, int rb, int re, void *out, const void *in)
     const int hi = g.row0 + g.Hb < g.H ? g.row0 + g.Hb + 1 : g.H;
     if (rb < lo || re > hi || rb > re) return fail(h, DS_ERR_ARG, "row range outside the band and its halo");
     if (rb == re) return DS_OK;
-    int rc = use_device(h);
+    int rc = need_current(h, out ? "ds_get_phi" : "ds_set_phi");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     return guarded(h, [&]() -> int {
         if (h->dtype == DS_F64)
@@ -847,7 +873,8 @@ int ds_iterate_raster(ds_handle *h, int n_iters)
     const ds::Geometry &g = h->g;
     if (g.row0 != 0 || g.Hb != g.H)
         return fail(h, DS_ERR_STATE, "ds_iterate_raster needs the whole image");
-    int rc = use_device(h);
+    int rc = need_current(h, "ds_iterate_raster");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     // H + W - 1 dependent launches per iteration.  Replaying them from a recorded HIP graph
     // was measured and changes nothing (35.3 vs 35.4 ms per iteration at 4K x 256): the cost
@@ -860,33 +887,44 @@ int ds_iterate_raster(ds_handle *h, int n_iters)
     return DS_OK;
 }
 
-int ds_energy(ds_handle *h, double *energy, double *max_residual)
+// The energy launches: two first-stage launches (one per colour) into part_sum / part_max
+// [0, part_n), a 1024-block reduction into block_sum / block_max, a one-block reduction into
+// result[0] (energy) and result[1] (largest |f_t(d)|).  Queued on the handle's stream.
+static int launch_energy(ds_handle *h, double *part_sum, double *part_max, double *block_sum, double *block_max,
+                         double *result)
 {
-    if (!h) return DS_ERR_ARG;
-    if (!energy) return fail(h, DS_ERR_ARG, "energy is NULL");
-    int rc = use_device(h);
-    if (rc != DS_OK) return rc;
     const dim3 grid(h->grid_x, h->g.Hb), block(ds::kBlock);
     const long long half = h->part_n / 2;
     for (int colour = 0; colour < 2; ++colour) {
-        rc = dispatch(h, [&](auto t, auto lpp) -> int {
+        int rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
             hipLaunchKernelGGL((ds::energy_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream,
                                h->g, static_cast<const T *>(h->phi), h->cost_px, (T)h->lambda, colour,
-                               h->seg_pixels, h->part_sum + colour * half, h->part_max + colour * half);
+                               h->seg_pixels, part_sum + colour * half, part_max + colour * half);
             return DS_OK;
         });
         if (rc != DS_OK) return rc;
         HIPCHK(h, hipGetLastError());
     }
     const long long chunk = (h->part_n + kReduceBlocks - 1) / kReduceBlocks;
-    hipLaunchKernelGGL(ds::reduce_partials_kernel, dim3(kReduceBlocks), block, 0, h->stream, h->part_sum,
-                       h->part_max, h->part_n, chunk, h->part_sum + h->part_n, h->part_max + h->part_n);
+    hipLaunchKernelGGL(ds::reduce_partials_kernel, dim3(kReduceBlocks), block, 0, h->stream, part_sum, part_max,
+                       h->part_n, chunk, block_sum, block_max);
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(ds::reduce_partials_kernel, dim3(1), block, 0, h->stream, h->part_sum + h->part_n,
-                       h->part_max + h->part_n, (long long)kReduceBlocks, (long long)kReduceBlocks,
-                       h->d_scalars, h->d_scalars + 1);
+    hipLaunchKernelGGL(ds::reduce_partials_kernel, dim3(1), block, 0, h->stream, block_sum, block_max,
+                       (long long)kReduceBlocks, (long long)kReduceBlocks, result, result + 1);
     HIPCHK(h, hipGetLastError());
+    return DS_OK;
+}
+
+int ds_energy(ds_handle *h, double *energy, double *max_residual)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!energy) return fail(h, DS_ERR_ARG, "energy is NULL");
+    int rc = need_current(h, "ds_energy");
+    if (rc == DS_OK) rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    rc = launch_energy(h, h->part_sum, h->part_max, h->part_sum + h->part_n, h->part_max + h->part_n, h->d_scalars);
+    if (rc != DS_OK) return rc;
     double host[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(host, h->d_scalars, sizeof host, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -900,7 +938,8 @@ int ds_labels(ds_handle *h, int mode, uint32_t *out)
     if (!h) return DS_ERR_ARG;
     if (!out) return fail(h, DS_ERR_ARG, "out is NULL");
     if (mode != 0 && mode != 1) return fail(h, DS_ERR_ARG, "mode must be 0 or 1");
-    int rc = use_device(h);
+    int rc = need_current(h, "ds_labels");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     const dim3 grid(h->grid_x, h->g.Hb), block(ds::kBlock);
     for (int colour = 0; colour < 2; ++colour) {
@@ -1053,19 +1092,34 @@ int ds_co_begin(ds_handle *h, double epsilon)
     if (!h) return DS_ERR_ARG;
     if (!(epsilon >= 0.0)) return fail(h, DS_ERR_ARG, "epsilon must be >= 0");
     const ds::Geometry &g = h->g;
-    int rc = use_device(h);
+    int rc = need_current(h, "ds_co_begin");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     const size_t mask_bytes = (size_t)(2 * ds::mask_colour_stride(g));
-    if (!h->co_alive) {
-        hipError_t e = hipMalloc(&h->co_alive, mask_bytes);
-        if (e == hipSuccess) e = hipMalloc(&h->co_gmin, (size_t)2 * g.Hb * g.Wh * 4 * h->elem);
-        if (e == hipSuccess) e = hipMalloc(&h->co_flags, 2 * sizeof(int));
-        if (e != hipSuccess)
+    h->co_begun = false;
+    if (!h->co_alive || !h->co_gmin || !h->co_flags) {
+        // all three or none: a failure must not leave a half-allocated state behind that a
+        // later call would take for complete
+        void *alive = nullptr, *gmin = nullptr, *flags = nullptr;
+        hipError_t e = hipMalloc(&alive, mask_bytes);
+        if (e == hipSuccess) e = hipMalloc(&gmin, (size_t)2 * g.Hb * g.Wh * 4 * h->elem);
+        if (e == hipSuccess) e = hipMalloc(&flags, 2 * sizeof(int));
+        if (e != hipSuccess) {
+            (void)hipFree(alive);
+            (void)hipFree(gmin);
+            (void)hipFree(flags);
+            (void)hipGetLastError();
             return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP,
                         std::string("hipMalloc(crossing-out state): ") + hipGetErrorString(e));
+        }
+        (void)hipFree(h->co_alive);
+        (void)hipFree(h->co_gmin);
+        (void)hipFree(h->co_flags);
+        h->co_alive = static_cast<uint8_t *>(alive);
+        h->co_gmin = gmin;
+        h->co_flags = static_cast<int *>(flags);
     }
     h->co_epsilon = epsilon;
-    h->co_begun = true;
     const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
     HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
     // Halo rows start all-alive: until the neighbouring band's rows arrive they must not
@@ -1087,6 +1141,7 @@ int ds_co_begin(ds_handle *h, double epsilon)
         if (rc != DS_OK) return rc;
         HIPCHK(h, hipGetLastError());
     }
+    h->co_begun = true;
     return DS_OK;
 }
 
@@ -1274,7 +1329,8 @@ int ds_epsilon_gaps(ds_handle *h, size_t *count, int *largest_repeated)
     if (!count) return fail(h, DS_ERR_ARG, "count is NULL");
     const ds::Geometry &g = h->g;
     if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_epsilon_gaps needs the whole image");
-    int rc = use_device(h);
+    int rc = need_current(h, "ds_epsilon_gaps");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     eps_release(h);
     const size_t n = (size_t)g.H * g.W * g.D * (1 + 4 * (size_t)g.D);
@@ -1379,7 +1435,8 @@ int ds_checksum(ds_handle *h, uint64_t *out)
 {
     if (!h) return DS_ERR_ARG;
     if (!out) return fail(h, DS_ERR_ARG, "out is NULL");
-    int rc = use_device(h);
+    int rc = need_current(h, "ds_checksum");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_checksum, 0, sizeof(unsigned long long), h->stream));
     long long blocks = (8 * h->plane_elems + ds::kBlock - 1) / ds::kBlock;

@@ -807,7 +807,7 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
 // ---- energy and residual ----------------------------------------------------------
 // Per pixel: min_d f_t(d) + sum over slots 2,3 of min_d( phi[t][n][d] + M_n(d) )
 // (diffusion_graph.rs:456-518; min_{d,d'} g evaluated as min_d of phi + M).  Each
-// wavefront writes one partial sum (f64) and one partial max |f_t(d)|.
+// block writes one partial sum (f64) and one partial max |f_t(d)|.
 template <typename T, int LPP>
 __device__ __forceinline__ T segment_min(T v)
 {
@@ -876,17 +876,30 @@ __global__ __launch_bounds__(kBlock) void energy_kernel(Geometry g, const T *__r
             worst = worst > (double)fabsmax ? worst : (double)fabsmax;
         }
     }
-    // fixed-order wavefront reduction (lane 0 ends with the total)
+    // fixed-order reduction: lane 0 of each wavefront ends with the wavefront's total, then the
+    // block's four totals are added in wavefront order
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         sum += __shfl_down(sum, m);
         const double o = __shfl_down(worst, m);
         worst = worst > o ? worst : o;
     }
+    __shared__ double wave_sum[kBlock / 64], wave_max[kBlock / 64];
     if (lane == 0) {
-        const long long slot = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave;
-        part_sum[slot] = sum;
-        part_max[slot] = worst;
+        wave_sum[wave] = sum;
+        wave_max[wave] = worst;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = wave_sum[0], m = wave_max[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) {
+            s += wave_sum[w];
+            m = m > wave_max[w] ? m : wave_max[w];
+        }
+        const long long slot = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        part_sum[slot] = s;
+        part_max[slot] = m;
     }
 }
 

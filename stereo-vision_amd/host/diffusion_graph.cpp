@@ -63,6 +63,7 @@ DiffusionGraph &DiffusionGraph::operator=(DiffusionGraph &&o) noexcept
         phi_ = std::move(o.phi_);
         host_valid_ = o.host_valid_;
         host_dirty_ = o.host_dirty_;
+        raster_order = o.raster_order;
     }
     return *this;
 }

@@ -59,6 +59,34 @@ def test_cli_raster_schedule_reproduces_sequential_run(tmp_path, golden_dir):
     assert abs(float(last_energy.split()[1]) - float(gold["energy_seq"])) <= 1e-9 * abs(float(gold["energy_seq"]))
 
 
+@pytest.mark.parametrize("decode", ["crossing", "crossing-host", "belief"])
+def test_cli_schedule_flag_reaches_every_decode_mode(tmp_path, golden_dir, decode):
+    """The two schedules end at the same map on the bundled pair, so only the energies of the
+    first iterations tell them apart: with --schedule raster they must follow the sequential
+    restatement (and differ from the red-black values), whatever --decode is chosen."""
+    left, _, _ = pyoracle.pgm_reader(os.path.join(golden_dir, "left.pgm"))
+    right, _, _ = pyoracle.pgm_reader(os.path.join(golden_dir, "right.pgm"))
+    seq, cb = pyoracle.OracleGraph(left, right, 40, 1.2), pyoracle.OracleGraph(left, right, 40, 1.2)
+    want = {"raster": [], "red-black": []}
+    for _ in range(3):
+        seq.diffusion_act()
+        cb.diffusion_act_checkerboard()
+        want["raster"].append(float(seq.energy()))
+        want["red-black"].append(float(cb.energy()))
+    assert abs(want["raster"][0] - want["red-black"][0]) > 0.1  # the schedules are distinguishable
+    for schedule in ("raster", "red-black"):
+        run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
+                              os.path.join(golden_dir, "right.pgm"), str(tmp_path / "o.pgm"), "--schedule", schedule,
+                              "--decode", decode, "--iterations", "3", "--batch", "3", "--max-batches", "1",
+                              "--epsilon", "100"],
+                             capture_output=True, text=True, timeout=100, cwd=str(tmp_path))
+        assert run.returncode == 0, run.stdout + run.stderr
+        got = [float(ln.split()[1]) for ln in run.stdout.splitlines() if ln.startswith("Energy: ")]
+        assert len(got) >= 4, run.stdout
+        for k in range(3):
+            assert abs(got[1 + k] - want[schedule][k]) <= 1e-9 * abs(want[schedule][k]), (schedule, decode, k, got)
+
+
 def test_cli_epsilon_search(tmp_path, golden_dir):
     """--decode epsilon-search against the oracle's restatement of epsilon_search.rs on the
     same phi (red-black oracle, 60 iterations on the bundled pair)."""

@@ -35,15 +35,32 @@ def test_pair_equals_two_launches(dtype, D):
     a.sweep(0, 5, 6)
     b.sweep_pair(0, False, (5, 6), (8, 8))
     assert np.array_equal(a.get_phi(), b.get_phi())
-    # into the planes the next whole-iteration kernel produces, then that kernel over the rest
-    fb, fe = a.fused_rows()
-    assert (fb, fe) == (0, H)
-    a.sweep_next(0, 1)
-    a.sweep_next(H - 1, H)
-    b.sweep_pair(1, True, (0, 1), (H - 1, H))
+    phi = a.get_phi()
+    a.close()
+    b.close()
+    # into the planes the next whole-iteration kernel produces, then that kernel over the rest:
+    # a band with a neighbour on either side leaves its first and last row to the half-sweeps
+    from stereo_vision_amd import diffstereo
+    left, right = random_pair(H, W, seed=21)
+    a, b = [diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype, row_begin=1, row_end=H - 1) for _ in range(2)]
     for g in (a, b):
-        g.iterate_rows(1, H - 1)
+        g.set_phi(phi, 0, H)  # own rows and both halo rows
+    fb, fe = a.fused_rows()
+    assert (fb, fe) == (2, H - 2)
+    a.sweep(0, 1, 3)
+    a.sweep(0, H - 3, H - 1)
+    a.sweep_next(1, 2)
+    a.sweep_next(H - 2, H - 1)
+    b.sweep_pair(0, False, (1, 3), (H - 3, H - 1))
+    b.sweep_pair(1, True, (1, 2), (H - 2, H - 1))
+    for g in (a, b):
+        with pytest.raises(diffstereo.DiffStereoError):
+            g.iterate_rows(fb + 1, fe)  # a part of the range would leave stale rows behind
+        g.iterate_rows(fb, fe)
+        with pytest.raises(diffstereo.DiffStereoError):
+            g.checksum()                # the first colour's planes are out of date
         g.finish_iterations()
+        g.finish_iterations()           # nothing pending: a no-op
     assert np.array_equal(a.get_phi(), b.get_phi())
     assert a.checksum() == b.checksum()
     a.close()

@@ -42,6 +42,16 @@ def rel_err(a, b):
     return float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
 
 
+def elem_err(a, b):
+    """max over elements of |a-b| / max(1, |b|): element-wise relative error (every entry is
+    held to the tolerance against its own magnitude, not against the largest one)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())
+
+
 class NumpyCrossingOut:
     """Vectorised restatement of CrossingOutGraph::initialize_with_epsilon + crossing_out
     (crossing_out_graph.rs:67-183) with explicit [D][D] edge tables, for the rows
