@@ -147,6 +147,20 @@ int ds_sweep(ds_handle *h, int colour, int row_begin, int row_end);
  * image's energy.  *max_residual (may be NULL) receives max |f_t(d)| over the band. */
 int ds_energy(ds_handle *h, double *energy, double *max_residual);
 
+/* ds_energy for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The reduction's
+ * partial sums live in a static device array of the library (64 MiB per GPU, held until the
+ * process ends) instead of the handle's buffers; the call allocates nothing, copies nothing and
+ * does not synchronise: it queues four kernels on the handle's stream, the last of which writes
+ * result_dev[0] = energy and result_dev[1] = max |f_t(d)|.  result_dev: two doubles of device
+ * memory or pinned host memory, owned by the caller (anything else is DS_ERR_ARG).
+ * Limit: the handle may need at most 4 194 304 partial sums (2 x blocks per row x rows of the
+ * band: a whole 3840 x 2160 x 256 image needs 2 073 600); larger handles get DS_ERR_ARG.
+ * All calls on one GPU share the array: calls that overlap in time on one GPU (two handles
+ * on different streams) race; calls on one stream, or ordered by the caller, do not.
+ * Same value as ds_energy, bit for bit (same kernels, same order of summation). */
+int ds_energy_static(ds_handle *h, double *result_dev);
+
 /* Stage 3.  mode 1 replaces min_penalty_vertex / build_depth_map
  * (diffusion_graph.rs:376-390,456-470): argmin_d f_t(d), first minimum wins.
  * mode 0 takes the same argmin of f_t as it stands after the pixel's vertex step

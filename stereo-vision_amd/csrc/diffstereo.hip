@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -25,6 +26,20 @@ thread_local std::string g_create_error;
 }  // namespace
 
 constexpr int kReduceBlocks = 1024;  // first-stage blocks of the energy reduction
+
+// Scratch of ds_energy_static: the energy reduction's partials in memory that exists from load
+// time, so that the call allocates nothing.  Layout (doubles): [0, kStaticPartials) block sums,
+// then kReduceBlocks first-stage sums, then the same two ranges for the maxima.  Every GPU the
+// library runs on holds its own copy (64 MiB) until the process ends.  In host code the array's
+// name is only a handle for hipGetSymbolAddress: kernels and memsets get the per-device address
+// kept in g_scratch_ptr.
+constexpr long long kStaticPartials = 1ll << 22;
+constexpr long long kStaticDoubles = 2 * (kStaticPartials + kReduceBlocks);
+static __device__ __align__(256) double scratch[kStaticDoubles];
+
+constexpr int kMaxDevices = 64;
+static double *g_scratch_ptr[kMaxDevices];  // per device, set once by scratch_for_device()
+static std::mutex g_scratch_mutex;
 
 struct ds_handle {
     ds::Geometry g{};
@@ -145,6 +160,21 @@ int planes_per_group(const ds_handle *h) { return h->fused_waves ? 6 : 4; }
 int use_device(ds_handle *h)
 {
     HIPCHK(h, hipSetDevice(h->device));
+    return DS_OK;
+}
+
+// Address of the current device's copy of `scratch`, looked up once per device.
+int scratch_for_device(ds_handle *h, int device, double **out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(h, DS_ERR_ARG, "device index beyond the library's table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail_hip(h, "hipGetSymbolAddress(scratch)", e);
+        g_scratch_ptr[device] = static_cast<double *>(p);
+    }
+    if (out) *out = g_scratch_ptr[device];
     return DS_OK;
 }
 
@@ -522,6 +552,7 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
         return rc;
     };
     int rc = use_device(h);
+    if (rc == DS_OK) rc = scratch_for_device(h, h->device, nullptr);  // once per device, with it current
     if (rc != DS_OK) return bail(rc);
 
     ds::Geometry &g = h->g;
@@ -931,6 +962,34 @@ int ds_energy(ds_handle *h, double *energy, double *max_residual)
     *energy = host[0];
     if (max_residual) *max_residual = host[1];
     return DS_OK;
+}
+
+int ds_energy_static(ds_handle *h, double *result_dev)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!result_dev) return fail(h, DS_ERR_ARG, "result_dev is NULL");
+    if (h->part_n > kStaticPartials)
+        return fail(h, DS_ERR_ARG,
+                    "ds_energy_static: this handle needs " + std::to_string(h->part_n) +
+                        " partial sums, the static scratch holds " + std::to_string(kStaticPartials) +
+                        " (use ds_energy, or a band with fewer rows)");
+    int rc = need_current(h, "ds_energy_static");
+    if (rc == DS_OK) rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    // the two doubles are written by a kernel: pageable host memory would fault it
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, result_dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(h, DS_ERR_ARG, "ds_energy_static: result_dev must be device memory or pinned host memory");
+    }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged)
+        return fail(h, DS_ERR_ARG, "ds_energy_static: result_dev must be device memory or pinned host memory");
+    double *base = (h->device >= 0 && h->device < kMaxDevices) ? g_scratch_ptr[h->device] : nullptr;
+    if (!base) return fail(h, DS_ERR_STATE, "ds_energy_static: no scratch address for this device");
+    double *sums = base, *maxes = base + kStaticPartials + kReduceBlocks;
+    // Nothing needs clearing: every entry the reductions read ([0, part_n) and the kReduceBlocks
+    // block results) is written earlier in this same call.
+    return launch_energy(h, sums, maxes, sums + kStaticPartials, maxes + kStaticPartials, result_dev);
 }
 
 int ds_labels(ds_handle *h, int mode, uint32_t *out)

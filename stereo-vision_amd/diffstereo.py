@@ -39,6 +39,7 @@ SYMBOLS = {
     "ds_halo_next": (_I, [_P, _I, _I, _PP, C.POINTER(C.c_size_t)]),
     "ds_finish_iterations": (_I, [_P]),
     "ds_energy": (_I, [_P, _DP, _DP]),
+    "ds_energy_static": (_I, [_P, _P]),
     "ds_labels": (_I, [_P, _I, _P]),
     "ds_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
     "ds_find_best_labeling": (_I, [_P, _I, _P, _IP, C.POINTER(C.c_longlong)]),
@@ -189,6 +190,11 @@ class DiffusionGraph:
         e, r = C.c_double(), C.c_double()
         self._chk(lib().ds_energy(self._h, C.byref(e), C.byref(r)))
         return (e.value, r.value) if with_residual else e.value
+
+    def energy_static(self, result_dev_ptr):
+        """ds_energy without any allocation: queues the reduction on the handle's stream; its
+        last kernel writes (energy, max residual) to the two doubles at the device pointer."""
+        self._chk(lib().ds_energy_static(self._h, C.c_void_p(result_dev_ptr)))
 
     def labels(self, mode=0):
         out = np.empty((self.rows, self.W), dtype=np.uint32)
