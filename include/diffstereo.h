@@ -251,6 +251,87 @@ int ds_set_phi(ds_handle *h, const void *in);
  * device buffers of *bytes bytes with identical internal layout on both sides. */
 int ds_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_t *bytes);
 
+/* ---- Row bands over the GPUs of a node: one process (rank) per GPU ------------------------
+ *
+ * No counterpart in the reference, which is one process with one raster loop
+ * (diffusion_stereo/src/diffusion_graph.rs:264-293, main.rs:36-98); under the red-black
+ * schedule its image splits into horizontal bands that exchange one row of messages with each
+ * neighbouring band after each colour.  Rank r of `world` owns the r-th band (ds_create_band)
+ * and its neighbours are the ranks r - 1 and r + 1.  The entry points below run the whole
+ * protocol inside the library -- boundary rows first, on a stream of the library's own beside
+ * the kernel that updates the band's interior, the exchanges queued behind them, explicit
+ * events between the two streams (no stream priorities) -- so that a host only says
+ * "iterate".  Results are bit-identical to the unpartitioned image.
+ *
+ * The halo rows travel through a ds_transport.  The library's own is RCCL (ncclSend / ncclRecv
+ * inside ncclGroupStart / ncclGroupEnd on the boundary stream, ncclAllReduce for the scalars;
+ * librccl is loaded with dlopen when ds_comm_* is first used, so hosts that never use bands
+ * need not link it).  A host may plug in another transport (tests do: gloo through host
+ * memory, several ranks sharing one GPU). */
+typedef struct ds_comm ds_comm;
+
+enum { DS_COMM_ID_BYTES = 128 };
+enum { DS_REDUCE_SUM_F64 = 0, DS_REDUCE_MAX_F64 = 1, DS_REDUCE_MAX_I32 = 2, DS_REDUCE_MIN_I32 = 3 };
+
+typedef struct ds_transport {
+    void *ctx;
+    /* For k < n: send bytes[k] bytes of device memory at send[k] to rank peers[k] and receive
+     * as many from that rank into recv[k].  The n transfers form one group (no transfer may
+     * wait for another of the group; with the same peer twice, sends and receives match in
+     * order).  Stream-ordered on hip_stream: the data is read after the work queued there
+     * before the call, and work queued afterwards sees what was received (an implementation
+     * may simply block the host until that holds).  Returns 0 or non-zero. */
+    int (*exchange)(void *ctx, int n, const int *peers, void *const *send, void *const *recv,
+                    const size_t *bytes, void *hip_stream);
+    /* In-place reduction over all ranks of `count` values at dev (device memory), kind =
+     * DS_REDUCE_*; stream-ordered on hip_stream like exchange. */
+    int (*all_reduce)(void *ctx, void *dev, int count, int kind, void *hip_stream);
+    /* Text of the last failure (may be NULL). */
+    const char *(*last_error)(void *ctx);
+} ds_transport;
+
+/* RCCL communicator.  Rank 0 calls ds_comm_unique_id and hands the 128 bytes to the other
+ * ranks by whatever means the host has (a file, a socket, MPI, torch.distributed); then
+ * every rank calls ds_comm_create with its rank, the number of ranks and its HIP device
+ * (collective: returns when all ranks have called it). */
+int ds_comm_unique_id(uint8_t id[DS_COMM_ID_BYTES]);
+int ds_comm_create(const uint8_t id[DS_COMM_ID_BYTES], int rank, int world, int device, ds_comm **out);
+void ds_comm_destroy(ds_comm *c);
+const char *ds_comm_last_error(const ds_comm *c);
+
+/* Tells a band handle how its halo rows travel and who its neighbours are: up_rank owns the
+ * band above, down_rank the band below, -1 = none (the image's edge).  ds_band_attach_comm
+ * uses the library's RCCL transport (the communicator must outlive the handle's use of it);
+ * ds_band_attach copies the given table.  Creates the handle's boundary stream and events. */
+int ds_band_attach_comm(ds_handle *h, ds_comm *c, int up_rank, int down_rank);
+int ds_band_attach(ds_handle *h, const ds_transport *t, int up_rank, int down_rank);
+
+/* Brings both colours' halo rows up to date (after ds_set_phi on the bands).  Collective over
+ * the neighbouring ranks, synchronous at return. */
+int ds_band_exchange(ds_handle *h);
+
+/* n_iters x diffusion_act (diffusion_graph.rs:264-341) over all bands; every rank calls it
+ * with the same n_iters.  A band of 8 rows or more whose handle has the fused kernel runs, per
+ * iteration: on the boundary stream the first colour's two first / two last rows, their
+ * exchange, the second colour's first / last row into the planes the iteration is producing,
+ * their exchange; on the handle's stream, at the same time, the kernel that updates all other
+ * rows keeping the first colour on chip.  Shorter bands sweep colour by colour (boundary rows,
+ * exchange beside the interior rows).  Both kinds exchange the same messages, so they may be
+ * neighbours.  Synchronous at return; every other entry point sees the same state as after
+ * 2 n half-sweeps. */
+int ds_band_iterate(ds_handle *h, int n_iters);
+
+/* DiffusionGraph::energy (diffusion_graph.rs:502-518) of the whole image: ds_energy of the
+ * band, summed over the ranks (max_residual: maximum over the ranks; may be NULL). */
+int ds_band_energy(ds_handle *h, double *energy, double *max_residual);
+
+/* ds_crossing_out over all bands: ds_co_begin, the mask halo rows to the neighbours, then
+ * passes (each followed by a reduction of the two flags over the ranks and the mask halo
+ * exchange) until no band changed or some band lost a pixel; labels / alive_out cover this
+ * band's rows, *not_empty and *passes are the same on every rank. */
+int ds_band_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
+                         int *not_empty, int *passes);
+
 /* Per-launch timing of the sweep kernel with HIP events on the handle's stream.
  * ds_profile_begin clears the counters and enables timing (at most max_launches
  * launches are timed); ds_profile_end synchronises, disables timing and reports the

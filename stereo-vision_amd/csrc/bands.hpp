@@ -1,0 +1,494 @@
+// Row bands over several ranks, one process per GPU: the protocol that keeps the bands' halo
+// rows current while they iterate, the RCCL transport it uses by default, and the C entry
+// points for both (include/diffstereo.h, "Row bands over the GPUs of a node").
+//
+// Included at the end of diffstereo.hip: it uses that file's handle and launch helpers.
+//
+// The reference is one process with one raster loop (diffusion_stereo/src/diffusion_graph.rs:
+// 264-293).  Under the red-black schedule a pixel update reads only the four neighbours of
+// the other colour, so after each colour a band needs exactly one row from each neighbouring
+// band: the slot-3 (downward) messages of the row above it and the slot-1 (upward) messages
+// of the row below it.
+//
+// Streams.  Everything a band does for its neighbours -- the half-sweeps of its boundary rows
+// and the two exchanges of an iteration -- is queued on `side_stream`; the kernel that
+// updates the interior rows runs on the handle's stream.  The two are ordered by two events
+// only: the boundary chain of iteration n waits for the interior kernel of iteration n - 1
+// (ev_main) and the interior kernel of iteration n + 1 waits for the chain of iteration n
+// (ev_side).  Both streams have the default priority.  RCCL's kernel is queued on the boundary
+// stream itself, so no third stream and no cycle of waits exists: main -> side -> main.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct ds_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    std::string err;
+};
+
+namespace {
+
+// ---- librccl, loaded on first use ------------------------------------------------------
+struct RcclApi {
+    void *dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+std::mutex g_rccl_mutex;
+RcclApi g_rccl;
+thread_local std::string g_comm_error;
+
+// A copy that the process has loaded already (a host that also uses RCCL through another
+// library) is taken before a second one is mapped: two copies would each keep their own state.
+RcclApi *rccl()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.dl) return &g_rccl;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *dl = nullptr;
+    for (const char *n : names)
+        if ((dl = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+    if (!dl)
+        for (const char *n : names)
+            if ((dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!dl) {
+        g_rccl.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+        return nullptr;
+    }
+    auto sym = [&](const char *name) {
+        void *p = dlsym(dl, name);
+        if (!p) g_rccl.err = std::string("librccl lacks ") + name;
+        return p;
+    };
+    RcclApi a;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.Send || !a.Recv || !a.AllReduce ||
+        !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
+        dlclose(dl);
+        return nullptr;
+    }
+    a.dl = dl;
+    g_rccl = a;
+    return &g_rccl;
+}
+
+int comm_fail(ds_comm *c, const char *what, ncclResult_t r)
+{
+    RcclApi *api = rccl();
+    const std::string msg = std::string(what) + ": " + (api ? api->GetErrorString(r) : "librccl not loaded");
+    if (c) c->err = msg;
+    else g_comm_error = msg;
+    return 1;
+}
+
+// ---- the RCCL transport ----------------------------------------------------------------
+int rccl_exchange(void *ctx, int n, const int *peers, void *const *send, void *const *recv, const size_t *bytes,
+                  void *hip_stream)
+{
+    ds_comm *c = static_cast<ds_comm *>(ctx);
+    RcclApi *api = rccl();
+    if (!api || !c || !c->comm) return 1;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    ncclResult_t r = api->GroupStart();
+    if (r != ncclSuccess) return comm_fail(c, "ncclGroupStart", r);
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    for (int k = 0; k < n && first == ncclSuccess; ++k) {
+        first = api->Send(send[k], bytes[k], ncclUint8, peers[k], c->comm, s);
+        what = "ncclSend";
+        if (first != ncclSuccess) break;
+        first = api->Recv(recv[k], bytes[k], ncclUint8, peers[k], c->comm, s);
+        what = "ncclRecv";
+    }
+    r = api->GroupEnd();  // always closed, also after a failure inside the group
+    if (first != ncclSuccess) return comm_fail(c, what, first);
+    if (r != ncclSuccess) return comm_fail(c, "ncclGroupEnd", r);
+    return 0;
+}
+
+int rccl_all_reduce(void *ctx, void *dev, int count, int kind, void *hip_stream)
+{
+    ds_comm *c = static_cast<ds_comm *>(ctx);
+    RcclApi *api = rccl();
+    if (!api || !c || !c->comm) return 1;
+    ncclDataType_t type = ncclFloat64;
+    ncclRedOp_t op = ncclSum;
+    switch (kind) {
+    case DS_REDUCE_SUM_F64: break;
+    case DS_REDUCE_MAX_F64: op = ncclMax; break;
+    case DS_REDUCE_MAX_I32: type = ncclInt32; op = ncclMax; break;
+    case DS_REDUCE_MIN_I32: type = ncclInt32; op = ncclMin; break;
+    default: c->err = "unknown reduction kind"; return 1;
+    }
+    ncclResult_t r = api->AllReduce(dev, dev, (size_t)count, type, op, c->comm, static_cast<hipStream_t>(hip_stream));
+    if (r != ncclSuccess) return comm_fail(c, "ncclAllReduce", r);
+    return 0;
+}
+
+const char *rccl_last_error(void *ctx) { return ctx ? static_cast<ds_comm *>(ctx)->err.c_str() : ""; }
+
+// ---- the protocol ------------------------------------------------------------------------
+int transport_fail(ds_handle *h, const char *what)
+{
+    const char *text = h->transport.last_error ? h->transport.last_error(h->transport.ctx) : nullptr;
+    return fail(h, DS_ERR_STATE, std::string(what) + " failed in the transport" + (text && *text ? std::string(": ") + text : ""));
+}
+
+int need_attached(ds_handle *h, const char *who)
+{
+    if (!h->attached) return fail(h, DS_ERR_STATE, std::string(who) + " before ds_band_attach");
+    return DS_OK;
+}
+
+// Work queued on `from` so far happens before work queued on `to` from now on.
+int order(ds_handle *h, hipStream_t from, hipEvent_t ev, hipStream_t to)
+{
+    HIPCHK(h, hipEventRecord(ev, from));
+    HIPCHK(h, hipStreamWaitEvent(to, ev, 0));
+    return DS_OK;
+}
+
+// Launches of the library go to h->stream: run `body` with the boundary stream in its place.
+template <typename F> int on_side(ds_handle *h, F &&body)
+{
+    hipStream_t keep = h->stream;
+    h->stream = h->side_stream;
+    const int rc = body();
+    h->stream = keep;
+    return rc;
+}
+
+// Halo row of phi: device pointer and size (see ds_halo).  upcoming = the colour-1 planes the
+// running iteration is producing instead of the current ones.
+void halo_row(const ds_handle *h, int colour, bool upcoming, int side, int which, void **ptr, size_t *bytes)
+{
+    const ds::Geometry &g = h->g;
+    const int slot = side == 0 ? (which == 0 ? 1 : 3) : (which == 0 ? 3 : 1);
+    const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
+    const long long plane = upcoming ? h->alt_off[slot] : g.plane_off[colour][slot];
+    *ptr = static_cast<char *>(h->phi) + (size_t)(plane + (long long)il * g.row_stride) * h->elem;
+    *bytes = (size_t)g.Wh * g.Dpad * h->elem;
+}
+
+// The exchange that follows a colour's half-sweep, queued on `stream`.
+int exchange_phi(ds_handle *h, int colour, bool upcoming, hipStream_t stream)
+{
+    int peers[2], n = 0;
+    void *send[2], *recv[2];
+    size_t bytes[2];
+    for (int side = 0; side < 2; ++side) {
+        const int peer = side == 0 ? h->up : h->down;
+        if (peer < 0) continue;
+        peers[n] = peer;
+        halo_row(h, colour, upcoming, side, 0, &send[n], &bytes[n]);
+        halo_row(h, colour, upcoming, side, 1, &recv[n], &bytes[n]);
+        ++n;
+    }
+    if (n == 0) return DS_OK;
+    if (h->transport.exchange(h->transport.ctx, n, peers, send, recv, bytes, stream) != 0)
+        return transport_fail(h, "the halo exchange");
+    return DS_OK;
+}
+
+// One colour of a band that sweeps colour by colour: boundary rows, their exchange beside the
+// interior rows.
+int band_half_sweep(ds_handle *h, int colour)
+{
+    const int rb = h->g.row0, re = h->g.row0 + h->g.Hb;
+    const int top_end = h->up >= 0 ? (rb + 1 < re ? rb + 1 : re) : rb;
+    const int bot_begin = h->down >= 0 ? (re - 1 > top_end ? re - 1 : top_end) : re;
+    int rc = launch_sweep(h, colour, rb, top_end, nullptr, bot_begin, re);
+    if (rc == DS_OK) rc = order(h, h->stream, h->ev_main, h->side_stream);
+    if (rc == DS_OK) rc = exchange_phi(h, colour, false, h->side_stream);
+    if (rc == DS_OK) rc = launch_sweep(h, colour, top_end, bot_begin);
+    if (rc == DS_OK) rc = order(h, h->side_stream, h->ev_side, h->stream);
+    return rc;
+}
+
+// One iteration of a band whose interior runs in the fused kernel.  The boundary chain and the
+// interior kernel read only the planes of the previous iteration and write disjoint rows.
+int band_fused_iteration(ds_handle *h, int fb, int fe)
+{
+    const int rb = h->g.row0, re = h->g.row0 + h->g.Hb;
+    // the chain reads what the previous interior kernel wrote, and writes the planes it read
+    int rc = order(h, h->stream, h->ev_main, h->side_stream);
+    if (rc != DS_OK) return rc;
+    rc = on_side(h, [&]() -> int {
+        const int t0 = rb, t1 = h->up >= 0 ? rb + 2 : rb;      // first colour: two rows next to each neighbour
+        const int b0 = h->down >= 0 ? re - 2 : re, b1 = re;
+        int r = launch_sweep(h, 0, t0, t1, nullptr, b0, b1);
+        if (r == DS_OK) r = exchange_phi(h, 0, false, h->side_stream);
+        if (r != DS_OK) return r;
+        ds::Geometry upcoming = h->g;                           // second colour: one row, into the planes
+        for (int s = 0; s < 4; ++s) upcoming.plane_off[1][s] = h->alt_off[s];  // this iteration produces
+        r = launch_sweep(h, 1, rb, h->up >= 0 ? rb + 1 : rb, &upcoming, h->down >= 0 ? re - 1 : re, re);
+        if (r == DS_OK) r = exchange_phi(h, 1, true, h->side_stream);
+        return r;
+    });
+    if (rc == DS_OK) rc = launch_fused(h, fb, fe);  // handle's stream; makes the produced planes current
+    if (rc == DS_OK) rc = order(h, h->side_stream, h->ev_side, h->stream);
+    return rc;
+}
+
+int reduce_scalar(ds_handle *h, void *dev, int count, int kind)
+{
+    if (h->up < 0 && h->down < 0) return DS_OK;  // a single band
+    if (h->transport.all_reduce(h->transport.ctx, dev, count, kind, h->stream) != 0)
+        return transport_fail(h, "the reduction over the ranks");
+    return DS_OK;
+}
+
+// Mask halo rows of the crossing-out, both colours, to both neighbours, in one group.
+int exchange_masks(ds_handle *h)
+{
+    const ds::Geometry &g = h->g;
+    int peers[4], n = 0;
+    void *send[4], *recv[4];
+    size_t bytes[4];
+    const size_t row = (size_t)g.Wh * g.Dpad;
+    for (int colour = 0; colour < 2; ++colour)
+        for (int side = 0; side < 2; ++side) {
+            const int peer = side == 0 ? h->up : h->down;
+            if (peer < 0) continue;
+            uint8_t *base = h->co_alive + colour * ds::mask_colour_stride(g);
+            peers[n] = peer;
+            send[n] = base + (size_t)(side == 0 ? 1 : g.Hb) * row;
+            recv[n] = base + (size_t)(side == 0 ? 0 : g.Hb + 1) * row;
+            bytes[n] = row;
+            ++n;
+        }
+    if (n == 0) return DS_OK;
+    if (h->transport.exchange(h->transport.ctx, n, peers, send, recv, bytes, h->stream) != 0)
+        return transport_fail(h, "the mask halo exchange");
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_comm_unique_id(uint8_t id[DS_COMM_ID_BYTES])
+{
+    if (!id) return DS_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == DS_COMM_ID_BYTES, "unique id size");
+    RcclApi *api = rccl();
+    if (!api) {
+        g_comm_error = g_rccl.err;
+        return DS_ERR_STATE;
+    }
+    ncclUniqueId u;
+    ncclResult_t r = api->GetUniqueId(&u);
+    if (r != ncclSuccess) {
+        comm_fail(nullptr, "ncclGetUniqueId", r);
+        return DS_ERR_HIP;
+    }
+    std::memcpy(id, u.internal, DS_COMM_ID_BYTES);
+    return DS_OK;
+}
+
+int ds_comm_create(const uint8_t id[DS_COMM_ID_BYTES], int rank, int world, int device, ds_comm **out)
+{
+    if (!out) return DS_ERR_ARG;
+    *out = nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) {
+        g_comm_error = "ds_comm_create: need 0 <= rank < world and an id";
+        return DS_ERR_ARG;
+    }
+    RcclApi *api = rccl();
+    if (!api) {
+        g_comm_error = g_rccl.err;
+        return DS_ERR_STATE;
+    }
+    if (device >= 0) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) {
+            g_comm_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+            return DS_ERR_HIP;
+        }
+    } else if (hipGetDevice(&device) != hipSuccess) {
+        g_comm_error = "hipGetDevice failed";
+        return DS_ERR_HIP;
+    }
+    ds_comm *c = new (std::nothrow) ds_comm();
+    if (!c) return DS_ERR_NOMEM;
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, DS_COMM_ID_BYTES);
+    ncclResult_t r = api->CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        comm_fail(nullptr, "ncclCommInitRank", r);
+        delete c;
+        return DS_ERR_HIP;
+    }
+    *out = c;
+    return DS_OK;
+}
+
+void ds_comm_destroy(ds_comm *c)
+{
+    if (!c) return;
+    RcclApi *api = rccl();
+    if (api && c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)api->CommDestroy(c->comm);
+    }
+    delete c;
+}
+
+const char *ds_comm_last_error(const ds_comm *c) { return c ? c->err.c_str() : g_comm_error.c_str(); }
+
+int ds_band_attach(ds_handle *h, const ds_transport *t, int up_rank, int down_rank)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!t || !t->exchange || !t->all_reduce) return fail(h, DS_ERR_ARG, "transport needs exchange and all_reduce");
+    const ds::Geometry &g = h->g;
+    if ((up_rank >= 0) != (g.row0 > 0) || (down_rank >= 0) != (g.row0 + g.Hb < g.H))
+        return fail(h, DS_ERR_ARG, "a band has a neighbour above / below exactly where the image continues");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    if (!h->ev_main) HIPCHK(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    if (!h->ev_side) HIPCHK(h, hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+    if (!h->d_flag) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->d_flag), sizeof(int));
+        if (e != hipSuccess) return fail_hip(h, "hipMalloc(flag)", e);
+    }
+    h->transport = *t;
+    h->up = up_rank;
+    h->down = down_rank;
+    h->attached = true;
+    return DS_OK;
+}
+
+int ds_band_attach_comm(ds_handle *h, ds_comm *c, int up_rank, int down_rank)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!c) return fail(h, DS_ERR_ARG, "communicator is NULL");
+    if (up_rank >= c->world || down_rank >= c->world) return fail(h, DS_ERR_ARG, "neighbour rank outside the communicator");
+    if (c->device != h->device) return fail(h, DS_ERR_ARG, "the communicator was created on another device than the handle");
+    ds_transport t;
+    t.ctx = c;
+    t.exchange = rccl_exchange;
+    t.all_reduce = rccl_all_reduce;
+    t.last_error = rccl_last_error;
+    return ds_band_attach(h, &t, up_rank, down_rank);
+}
+
+int ds_band_exchange(ds_handle *h)
+{
+    if (!h) return DS_ERR_ARG;
+    int rc = need_attached(h, "ds_band_exchange");
+    if (rc == DS_OK) rc = need_current(h, "ds_band_exchange");
+    if (rc == DS_OK) rc = use_device(h);
+    for (int colour = 0; colour < 2 && rc == DS_OK; ++colour) rc = exchange_phi(h, colour, false, h->stream);
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DS_OK;
+}
+
+int ds_band_iterate(ds_handle *h, int n_iters)
+{
+    if (!h) return DS_ERR_ARG;
+    if (n_iters < 0) return fail(h, DS_ERR_ARG, "n_iters must be >= 0");
+    int rc = need_attached(h, "ds_band_iterate");
+    if (rc == DS_OK) rc = need_current(h, "ds_band_iterate");
+    if (rc == DS_OK) rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    const ds::Geometry &g = h->g;
+    if (h->up < 0 && h->down < 0) return ds_iterate(h, n_iters);  // one band: the whole image
+    int fb = 0, fe = 0;
+    if (h->fused_waves) fused_safe_rows(h, &fb, &fe);
+    const bool fused = n_iters > 0 && fe - fb >= 4 && g.Hb >= 8;
+    if (fused) {
+        for (int it = 0; it < n_iters && rc == DS_OK; ++it) rc = band_fused_iteration(h, fb, fe);
+        if (rc == DS_OK) rc = materialise_first_colour(h, g.row0, g.row0 + g.Hb);
+    } else {
+        for (int it = 0; it < n_iters && rc == DS_OK; ++it)
+            for (int colour = 0; colour < 2 && rc == DS_OK; ++colour) rc = band_half_sweep(h, colour);
+    }
+    // also after a failure: nothing of this call may still be running when it returns
+    const hipError_t e1 = hipStreamSynchronize(h->side_stream), e2 = hipStreamSynchronize(h->stream);
+    if (rc != DS_OK) return rc;
+    if (e1 != hipSuccess) return fail_hip(h, "hipStreamSynchronize(boundary stream)", e1);
+    if (e2 != hipSuccess) return fail_hip(h, "hipStreamSynchronize", e2);
+    return DS_OK;
+}
+
+int ds_band_energy(ds_handle *h, double *energy, double *max_residual)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!energy) return fail(h, DS_ERR_ARG, "energy is NULL");
+    int rc = need_attached(h, "ds_band_energy");
+    if (rc == DS_OK) rc = need_current(h, "ds_band_energy");
+    if (rc == DS_OK) rc = use_device(h);
+    if (rc == DS_OK)
+        rc = launch_energy(h, h->part_sum, h->part_max, h->part_sum + h->part_n, h->part_max + h->part_n, h->d_scalars);
+    if (rc == DS_OK) rc = reduce_scalar(h, h->d_scalars, 1, DS_REDUCE_SUM_F64);
+    if (rc == DS_OK) rc = reduce_scalar(h, h->d_scalars + 1, 1, DS_REDUCE_MAX_F64);
+    if (rc != DS_OK) return rc;
+    double host[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(host, h->d_scalars, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *energy = host[0];
+    if (max_residual) *max_residual = host[1];
+    return DS_OK;
+}
+
+int ds_band_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
+                         int *not_empty, int *passes)
+{
+    if (!h) return DS_ERR_ARG;
+    if (max_passes < 1) return fail(h, DS_ERR_ARG, "max_passes must be >= 1");
+    int rc = need_attached(h, "ds_band_crossing_out");
+    if (rc == DS_OK) rc = ds_co_begin(h, epsilon);
+    if (rc == DS_OK) rc = exchange_masks(h);
+    if (rc != DS_OK) return rc;
+    int done = 0, flags[2] = {1, 0};
+    for (;;) {
+        rc = co_launch_pass(h);
+        if (rc == DS_OK) rc = reduce_scalar(h, h->co_flags, 2, DS_REDUCE_MAX_I32);
+        if (rc != DS_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(flags, h->co_flags, sizeof flags, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        ++done;
+        if (flags[1] || !flags[0]) break;  // some band lost a pixel, or no band changed: the same on every rank
+        if (done >= max_passes) return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
+        rc = exchange_masks(h);
+        if (rc != DS_OK) return rc;
+    }
+    int ok = 0;
+    rc = ds_co_finish(h, flags[1], labels, alive_out, &ok);
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_flag, &ok, sizeof ok, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `ok` is on this frame
+    rc = reduce_scalar(h, h->d_flag, 1, DS_REDUCE_MIN_I32);
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(&ok, h->d_flag, sizeof ok, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (not_empty) *not_empty = ok;
+    if (passes) *passes = done;
+    return DS_OK;
+}
+
+}  // extern "C"

@@ -90,6 +90,15 @@ struct ds_handle {
 
     hipStream_t own_stream = nullptr, stream = nullptr;
 
+    // row bands over several ranks (bands.hpp): how halo rows travel, who the neighbours are,
+    // and the stream / events that run a band's boundary rows beside its interior kernel
+    ds_transport transport{};
+    bool attached = false;
+    int up = -1, down = -1;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    int *d_flag = nullptr;  // one int on the device for the bands' agreement on not_empty
+
     bool prof = false;
     int prof_cap = 0, prof_n = 0;
     std::vector<hipEvent_t> events;
@@ -211,6 +220,13 @@ void release(ds_handle *h)
     (void)hipFree(h->co_state);
     (void)hipFree(h->eps_buf[0]);
     (void)hipFree(h->eps_buf[1]);
+    if (h->side_stream) {
+        (void)hipStreamSynchronize(h->side_stream);
+        (void)hipStreamDestroy(h->side_stream);
+    }
+    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
+    (void)hipFree(h->d_flag);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -1204,18 +1220,15 @@ int ds_co_begin(ds_handle *h, double epsilon)
     return DS_OK;
 }
 
-int ds_co_pass(ds_handle *h, int *changed, int *lost)
+// One relaxation pass over the band, queued on the handle's stream; the two flags (a vertex
+// died / a pixel has no vertex left) end up in h->co_flags on the device.
+static int co_launch_pass(ds_handle *h)
 {
-    if (!h) return DS_ERR_ARG;
-    if (!changed || !lost) return fail(h, DS_ERR_ARG, "changed / lost is NULL");
-    if (!h->co_begun) return fail(h, DS_ERR_STATE, "ds_co_pass before ds_co_begin");
     const ds::Geometry &g = h->g;
-    int rc = use_device(h);
-    if (rc != DS_OK) return rc;
     const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
     HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
     for (int colour = 0; colour < 2; ++colour) {
-        rc = dispatch(h, [&](auto t, auto lpp) -> int {
+        int rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
             hipLaunchKernelGGL((ds::co_relax_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
                                static_cast<const T *>(h->phi), (T)h->lambda, (T)h->co_epsilon, colour,
@@ -1225,6 +1238,17 @@ int ds_co_pass(ds_handle *h, int *changed, int *lost)
         if (rc != DS_OK) return rc;
         HIPCHK(h, hipGetLastError());
     }
+    return DS_OK;
+}
+
+int ds_co_pass(ds_handle *h, int *changed, int *lost)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!changed || !lost) return fail(h, DS_ERR_ARG, "changed / lost is NULL");
+    if (!h->co_begun) return fail(h, DS_ERR_STATE, "ds_co_pass before ds_co_begin");
+    int rc = use_device(h);
+    if (rc == DS_OK) rc = co_launch_pass(h);
+    if (rc != DS_OK) return rc;
     int host_flags[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1515,3 +1539,5 @@ int ds_checksum(ds_handle *h, uint64_t *out)
 }
 
 }  // extern "C"
+
+#include "bands.hpp"

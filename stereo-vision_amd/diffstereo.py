@@ -50,6 +50,16 @@ SYMBOLS = {
     "ds_co_pass": (_I, [_P, _IP, _IP]),
     "ds_co_halo": (_I, [_P, _I, _I, _I, _PP, C.POINTER(C.c_size_t)]),
     "ds_co_finish": (_I, [_P, _I, _P, _P, _IP]),
+    "ds_comm_unique_id": (_I, [_P]),
+    "ds_comm_create": (_I, [_P, _I, _I, _I, _PP]),
+    "ds_comm_destroy": (None, [_P]),
+    "ds_comm_last_error": (C.c_char_p, [_P]),
+    "ds_band_attach_comm": (_I, [_P, _P, _I, _I]),
+    "ds_band_attach": (_I, [_P, _P, _I, _I]),
+    "ds_band_exchange": (_I, [_P]),
+    "ds_band_iterate": (_I, [_P, _I]),
+    "ds_band_energy": (_I, [_P, _DP, _DP]),
+    "ds_band_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
     "ds_get_phi_rows": (_I, [_P, _I, _I, _P]),
     "ds_set_phi_rows": (_I, [_P, _I, _I, _P]),
     "ds_get_phi": (_I, [_P, _P]),
@@ -62,6 +72,20 @@ SYMBOLS = {
     "ds_placement_info": (_I, [_P, _IP, _DP, _IP]),
     "ds_checksum": (_I, [_P, C.POINTER(C.c_uint64)]),
 }
+
+# struct ds_transport (include/diffstereo.h): a host-supplied way to move halo rows
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+LAST_ERROR_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p)
+DS_REDUCE_SUM_F64, DS_REDUCE_MAX_F64, DS_REDUCE_MAX_I32, DS_REDUCE_MIN_I32 = 0, 1, 2, 3
+DS_COMM_ID_BYTES = 128
+
+
+class TransportStruct(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("exchange", EXCHANGE_FN), ("all_reduce", ALL_REDUCE_FN),
+                ("last_error", LAST_ERROR_FN)]
+
 
 _LIB = None
 
@@ -262,6 +286,35 @@ class DiffusionGraph:
         self._chk(lib().ds_co_finish(self._h, int(bool(empty)), _ptr(labels),
                                      _ptr(alive) if with_mask else None, C.byref(ne)))
         out = {"labels": labels, "not_empty": bool(ne.value)}
+        if with_mask:
+            out["alive"] = alive
+        return out
+
+    # row bands over several ranks: the protocol runs inside the library (include/diffstereo.h)
+    def band_attach_comm(self, comm_ptr, up_rank, down_rank):
+        self._chk(lib().ds_band_attach_comm(self._h, comm_ptr, int(up_rank), int(down_rank)))
+
+    def band_attach(self, transport_struct, up_rank, down_rank):
+        self._chk(lib().ds_band_attach(self._h, C.byref(transport_struct), int(up_rank), int(down_rank)))
+
+    def band_exchange(self):
+        self._chk(lib().ds_band_exchange(self._h))
+
+    def band_iterate(self, n_iters):
+        self._chk(lib().ds_band_iterate(self._h, int(n_iters)))
+
+    def band_energy(self, with_residual=False):
+        e, r = C.c_double(), C.c_double()
+        self._chk(lib().ds_band_energy(self._h, C.byref(e), C.byref(r)))
+        return (e.value, r.value) if with_residual else e.value
+
+    def band_crossing_out(self, epsilon, max_passes=1 << 30, with_mask=False):
+        labels = np.empty((self.rows, self.W), dtype=np.uint32)
+        alive = np.empty((self.rows, self.W, self.D), dtype=np.uint8) if with_mask else None
+        ne, n = C.c_int(), C.c_int()
+        self._chk(lib().ds_band_crossing_out(self._h, float(epsilon), int(max_passes), _ptr(labels),
+                                             _ptr(alive) if with_mask else None, C.byref(ne), C.byref(n)))
+        out = {"labels": labels, "not_empty": bool(ne.value), "passes": n.value}
         if with_mask:
             out["alive"] = alive
         return out

@@ -1,0 +1,144 @@
+"""The band protocol inside the library (ds_band_attach / ds_band_exchange / ds_band_iterate /
+ds_band_energy / ds_band_crossing_out) on ONE GPU, in the two ways one GPU allows:
+
+* several ranks (processes) share cuda:0, each owns a band, the halo rows travel through the
+  host-memory transport (bands.GlooTransport) -- everything but RCCL: the library's boundary
+  stream and events, fused and colour-by-colour bands side by side, the reductions;
+* one rank whose two neighbours are itself over the library's own RCCL transport (ds_comm_*,
+  ncclSend / ncclRecv to self inside a group): the image that results is not meaningful, but
+  it is deterministic, so the same loop with plain device copies must give the same bits.
+
+Bar: bit-identical to the unpartitioned image (phi, labels, masks); energy 1e-9."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from tests.util import random_pair, random_phi
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gloo_worker(rank, world, port, dtype, D, H, W, out):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(240, exit=True, file=sys.stderr)  # a stuck rank ends itself
+    import torch
+    import torch.distributed as dist
+    load_package()
+    from stereo_vision_amd import bands, diffstereo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        iters = 3
+        left, right = random_pair(H, W, seed=8)
+        phi0 = random_phi(H, W, D, dtype, seed=2)
+        rb, re = bands.partition_rows(H, world)[rank]
+        g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype, row_begin=rb, row_end=re, device=0)
+        g.set_phi(phi0[rb:re])
+        runner = bands.Bands(g, bands.GlooTransport(), rank, world)
+        runner.exchange_all()
+        runner.iterate(iters)
+        runner.iterate(0)
+        runner.iterate(1)
+        energy = runner.energy()
+        whole = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+        whole.set_phi(phi0)
+        whole.iterate(iters + 1)
+        same = np.array_equal(g.get_phi(), whole.get_phi()[rb:re])
+        e_ref = whole.energy()
+        e_ok = abs(energy - e_ref) <= 1e-9 * max(1.0, abs(e_ref))
+        co_ok = True
+        for eps in (4.0, 40.0):
+            got = runner.crossing_out(eps, with_mask=True)
+            want = whole.crossing_out(eps, with_mask=True)
+            co_ok = co_ok and np.array_equal(got["alive"], want["alive"][rb:re]) \
+                and np.array_equal(got["labels"], want["labels"][rb:re]) and got["not_empty"] == want["not_empty"]
+        if not (same and e_ok and co_ok):
+            print("rank", rank, "phi same:", same, "energy", energy, "ref", e_ref, "crossing-out", co_ok, flush=True)
+        out[rank] = (bool(same), bool(e_ok), bool(co_ok))
+        g.close()
+        whole.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dtype,D,H,W", [(2, "f32", 24, 13, 45), (3, "f64", 24, 13, 45), (2, "f32", 256, 29, 75),
+                                               (3, "f64", 140, 29, 75), (2, "f64", 64, 17, 130), (3, "f32", 100, 40, 33),
+                                               (3, "f32", 64, 23, 70), (4, "f64", 40, 33, 52)])
+def test_ranks_sharing_one_gpu(world, dtype, D, H, W):
+    """H = 13: bands of 4-7 rows sweep colour by colour; H = 29 and more: bands of 8 rows or more
+    run the fused kernel in their interior; H = 23 over three ranks (8, 8, 7 rows) and H = 33 over
+    four (9, 8, 8, 8) put both kinds next to each other."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gloo_worker, args=(world, _free_port(), dtype, D, H, W, out), nprocs=world, join=True)
+    for rank in range(world):
+        assert out[rank] == (True, True, True), "rank %d: %s" % (rank, out[rank])
+
+
+def _rccl_worker(rank, dtype, D, rows, out):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(240, exit=True, file=sys.stderr)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    load_package()
+    from stereo_vision_amd import bands, diffstereo
+    H, W, iters = 40, 96, 3
+    rb, re = rows
+    left, right = random_pair(H, W, seed=12)
+    phi0 = random_phi(H, W, D, dtype, seed=6)
+    a = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype, row_begin=rb, row_end=re, device=0)
+    b = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype, row_begin=rb, row_end=re, device=0)
+    for g in (a, b):
+        g.set_phi(phi0[rb - 1:re + 1], rb - 1, re + 1)
+    comm = bands.RcclComm(0, 1, 0)
+    runner = bands.Bands(a, comm, 0, 1, up=0, down=0)  # both neighbours are this rank
+    runner.iterate(iters)
+    e_a = runner.energy()                               # all-reduce over one rank
+    hip = C.CDLL("libamdhip64.so")
+    for _ in range(iters):
+        for colour in (0, 1):
+            b.sweep(colour)
+            b.synchronize()
+            for side in (0, 1):
+                sp, n = b.halo(colour, side, 0)
+                dp, m = b.halo(colour, side, 1)
+                assert n == m
+                assert hip.hipMemcpy(C.c_void_p(dp), C.c_void_p(sp), C.c_size_t(n), 3) == 0
+    # own rows in full; of the halo rows only the slot that travels (the others are never read,
+    # and differ between the library's two sets of colour-1 planes)
+    pa, pb = a.get_phi(rb - 1, re + 1), b.get_phi(rb - 1, re + 1)
+    same = (np.array_equal(pa[1:-1], pb[1:-1]) and np.array_equal(pa[0, :, 3], pb[0, :, 3])
+            and np.array_equal(pa[-1, :, 1], pb[-1, :, 1]))
+    moved = not np.array_equal(pa[0], phi0[rb - 1].astype(pa.dtype))
+    out[0] = (bool(same), bool(moved), a.checksum() == b.checksum(), e_a == b.energy())
+    a.close()
+    b.close()
+    comm.close()
+
+
+@pytest.mark.parametrize("dtype,D,rows", [("f32", 64, (13, 29)), ("f64", 64, (13, 29)), ("f32", 200, (13, 29)),
+                                          ("f64", 130, (13, 29)), ("f32", 256, (20, 26))])
+def test_rccl_self_exchange_matches_device_copies(dtype, D, rows):
+    """16-row bands: interior in the fused kernel, boundary rows by half-sweeps on the boundary
+    stream, both exchanges per iteration over RCCL; the 6-row band sweeps colour by colour."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(dtype, D, rows, out), nprocs=1, join=True)
+    assert out[0] == (True, True, True, True), out[0]
