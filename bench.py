@@ -17,6 +17,7 @@ faithful single-threaded CPU restatement of the reference rule, timed on this ho
 a bounded crop of the same workload).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import socket
@@ -38,6 +39,7 @@ from stereo_vision_amd import bands, diffstereo, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 WORKLOADS = {
     "4k_256": dict(H=2160, W=3840, D=256, dtype="f32"),
+    "4k_256_f64": dict(H=2160, W=3840, D=256, dtype="f64"),  # the reference's own precision: 102 GB of phi
     "1080p_128": dict(H=1080, W=1920, D=128, dtype="f32"),
     "8k_256_f64": dict(H=4320, W=7680, D=256, dtype="f64"),
     "8k_256_f32": dict(H=4320, W=7680, D=256, dtype="f32"),  # 204 GB of phi: one GPU holds it
@@ -155,18 +157,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    # Rehearsal on a one-GPU box (DS_BENCH_REHEARSAL=1): all ranks share device 0 and talk
-    # over gloo, because RCCL refuses two ranks on one device.  Never used for reported numbers.
+    # Rehearsal on a one-GPU box (DS_BENCH_REHEARSAL=1): all ranks share device 0 and their halo
+    # rows travel through host memory, because RCCL refuses two ranks on one device.  Never
+    # used for reported numbers.
     rehearsal = os.environ.get("DS_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # gloo is the control plane only (the communicator's id, barriers, the max over ranks);
+        # the halo rows travel over RCCL inside the library
+        dist.init_process_group("gloo")
+
+    def all_agree(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     wl = WORKLOADS[args.workload]
     H, W, D, dtype, lam = wl["H"], wl["W"], wl["D"], wl["dtype"], 1.2
@@ -178,32 +185,36 @@ def main():
         rb, re = bands.partition_rows(H, args.band_of)[0]
     graph = diffstereo.DiffusionGraph(left, right, D, lam, dtype=dtype, row_begin=rb, row_end=re,
                                       device=local_rank)
-    engine = bands.HipBandEngine(graph, stage_through_host=rehearsal)
-    runner = bands.BandRunner(engine, rank=rank, world=world)
-    transport = "none" if world == 1 else "RCCL send/recv, 1 row per neighbour per colour"
-    if rehearsal and world > 1:
-        transport = "REHEARSAL: gloo through host memory, all ranks on one GPU"
-        runner.exchange_all()
-    elif world > 1:
-        # Preflight: one halo exchange over RCCL.  If any rank cannot do it, every rank moves
-        # the halos through pinned host memory over gloo instead (slower, and said so in
-        # the output line) rather than losing the run.  The ranks agree through an RCCL
-        # all-reduce; the gloo group is only created if it is needed (it prints to stdout).
-        ok = 1
-        try:
+    transport, comm = "none", None
+    if world == 1:
+        # the whole image through ds_iterate; --band-of: the band's kernels without a neighbour
+        runner = bands.BandRunner(bands.HipBandEngine(graph), rank=0, world=1)
+    else:
+        if not rehearsal:
+            # Preflight, in steps every rank can fail at without leaving its peers inside a
+            # collective: can librccl be loaded; the communicator; one halo exchange.  If any rank
+            # fails, all ranks move the halo rows through host memory over gloo instead (slower,
+            # and said so in the output line) rather than losing the run.
+            probe = (C.c_uint8 * diffstereo.DS_COMM_ID_BYTES)()
+            ok = diffstereo.lib().ds_comm_unique_id(probe) == 0
+            if all_agree(ok):
+                try:
+                    comm = bands.RcclComm(rank, world, local_rank)
+                    runner = bands.Bands(graph, comm, rank, world)
+                    runner.exchange_all()
+                except Exception as exc:  # noqa: BLE001
+                    ok = False
+                    print("rank %d: RCCL halo exchange failed: %r" % (rank, exc), file=sys.stderr, flush=True)
+                ok = all_agree(ok)
+            if ok:
+                transport = comm.name
+            else:
+                comm = None
+        if comm is None:
+            host = bands.GlooTransport()
+            runner = bands.Bands(graph, host, rank, world)
             runner.exchange_all()
-            torch.cuda.synchronize()
-        except Exception as exc:  # noqa: BLE001
-            ok = 0
-            print("rank %d: RCCL halo exchange failed: %r" % (rank, exc), file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            gloo = dist.new_group(backend="gloo")
-            engine = bands.HipBandEngine(graph, stage_through_host=True)
-            runner = bands.BandRunner(engine, rank=rank, world=world, group=gloo)
-            runner.exchange_all()
-            transport = "gloo through host memory (RCCL point-to-point failed in the preflight)"
+            transport = ("REHEARSAL: all ranks on one GPU, " if rehearsal else "RCCL failed in the preflight: ") + host.name
 
     def fence():
         torch.cuda.synchronize()
@@ -220,17 +231,30 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = graph.profile_end()
+    my_elapsed = elapsed
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     energy = runner.energy()
+    # every rank's own account: its kernels by kind and what its wall time holds beyond them
+    # (exchanges and waiting for neighbours; the boundary chain runs beside the interior kernel)
+    mine = graph.profile_split()
+    fused_ms = mine["fused_ms"] / max(args.steps, 1)
+    sweeps_ms = mine["half_sweep_ms"] / max(args.steps, 1)
+    account = {"rank": rank, "rows": [rb, re], "wall_ms_per_step": my_elapsed / args.steps * 1e3,
+               "interior_kernel_ms_per_step": fused_ms, "half_sweeps_ms_per_step": sweeps_ms,
+               "launches": prof["launches"]}
+    per_rank = [account]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, account)
 
     if rank == 0:
         pl = valid_pairs(H, W, D) if args.band_of == 1 else valid_pairs(re - rb, W, D)
         elem = 4 if dtype == "f32" else 8
         my_pl = valid_pairs(re - rb, W, D)
-        split = graph.profile_split()
+        split = mine
         tname = "float" if dtype == "f32" else "double"
         if split["fused"]:
             # Whole iterations in one kernel: only the second colour's phi moves (4 rows read,
@@ -288,6 +312,8 @@ def main():
                          "rank": 0, "placement": graph.placement_info()},
             "energy": energy,
         }
+        if world > 1:
+            line["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(left, right, D, lam)
         print(json.dumps(line), flush=True)
