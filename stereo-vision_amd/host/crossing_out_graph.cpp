@@ -10,7 +10,9 @@ CrossingOutGraph CrossingOutGraph::initialize(DiffusionGraph g, bool on_device)
 {
     CrossingOutGraph c(std::move(g));
     c.on_device_ = on_device;
-    c.H_ = c.diffusion_graph.height();
+    if (c.diffusion_graph.banded() && !on_device)
+        throw std::logic_error("a band keeps its masks on the device (initialize(..., true))");
+    c.H_ = c.diffusion_graph.rows();  // a band's masks cover its own rows
     c.W_ = c.diffusion_graph.width();
     c.D_ = c.diffusion_graph.max_disparity;
     c.vertices_.assign(c.H_ * c.W_ * c.D_, 1);
@@ -232,6 +234,7 @@ void CrossingOutGraph::cross_vertex(std::size_t i, std::size_t j, std::size_t di
 
 Matrix CrossingOutGraph::find_best_labeling()
 {
+    if (diffusion_graph.banded()) throw std::logic_error("find_best_labeling walks the whole image: one process only");
     if (on_device_) {
         // The masks live on the GPU since the last consistent_with_epsilon /
         // diffusion_while_not_consistent.  Without one, every vertex and edge is alive, as

@@ -17,6 +17,14 @@ DiffusionGraph DiffusionGraph::initialize(const std::vector<std::vector<std::uin
                                           const std::vector<std::vector<std::uint32_t>> &right_image,
                                           std::size_t max_disparity, double smoothing_term, int dtype)
 {
+    return initialize_band(left_image, right_image, max_disparity, smoothing_term, dtype, 0, left_image.size(), -1);
+}
+
+DiffusionGraph DiffusionGraph::initialize_band(const std::vector<std::vector<std::uint32_t>> &left_image,
+                                               const std::vector<std::vector<std::uint32_t>> &right_image,
+                                               std::size_t max_disparity, double smoothing_term, int dtype,
+                                               std::size_t row_begin, std::size_t row_end, int device)
+{
     if (left_image.empty() || left_image.size() != right_image.size() ||
         left_image[0].size() != right_image[0].size())
         throw std::invalid_argument("left and right images must have the same non-empty shape");
@@ -39,10 +47,24 @@ DiffusionGraph DiffusionGraph::initialize(const std::vector<std::vector<std::uin
             r[i * g.W_ + j] = static_cast<std::uint8_t>(right_image[i][j]);
         }
     }
-    int rc = ds_create(l.data(), r.data(), (int)g.H_, (int)g.W_, (int)max_disparity, smoothing_term, dtype,
-                       &g.h_);
+    if (row_begin >= row_end || row_end > g.H_) throw std::invalid_argument("band outside the image");
+    g.row_begin_ = row_begin;
+    g.rows_ = row_end - row_begin;
+    g.banded_ = g.rows_ != g.H_;
+    int rc = ds_create_band(l.data(), r.data(), (int)g.H_, (int)g.W_, (int)max_disparity, smoothing_term, dtype,
+                            (int)row_begin, (int)row_end, device, &g.h_);
     if (rc != DS_OK) throw std::runtime_error(std::string("diffstereo: ") + ds_last_error(nullptr));
     return g;
+}
+
+void DiffusionGraph::attach(ds_comm *comm, int up_rank, int down_rank)
+{
+    check(ds_band_attach_comm(h_, comm, up_rank, down_rank));
+}
+
+void DiffusionGraph::attach(const ds_transport &transport, int up_rank, int down_rank)
+{
+    check(ds_band_attach(h_, &transport, up_rank, down_rank));
 }
 
 DiffusionGraph::DiffusionGraph(DiffusionGraph &&o) noexcept { *this = std::move(o); }
@@ -64,6 +86,9 @@ DiffusionGraph &DiffusionGraph::operator=(DiffusionGraph &&o) noexcept
         host_valid_ = o.host_valid_;
         host_dirty_ = o.host_dirty_;
         raster_order = o.raster_order;
+        row_begin_ = o.row_begin_;
+        rows_ = o.rows_;
+        banded_ = o.banded_;
     }
     return *this;
 }
@@ -72,6 +97,7 @@ DiffusionGraph::~DiffusionGraph() { ds_destroy(h_); }
 
 void DiffusionGraph::pull()
 {
+    whole_image_only("the host copy of the potentials");
     if (host_valid_) return;
     const std::size_t n = H_ * W_ * 4 * max_disparity;
     phi_.resize(n);
@@ -205,10 +231,19 @@ double DiffusionGraph::min_penalty_edge(std::size_t i, std::size_t j, std::size_
     return m;
 }
 
+int DiffusionGraph::iterate(int n)
+{
+    if (banded_) {
+        if (raster_order) throw std::logic_error("the raster order needs the whole image in one process");
+        return ds_band_iterate(h_, n);
+    }
+    return raster_order ? ds_iterate_raster(h_, n) : ds_iterate(h_, n);
+}
+
 void DiffusionGraph::diffusion_act()
 {
     push();
-    check(raster_order ? ds_iterate_raster(h_, 1) : ds_iterate(h_, 1));
+    check(iterate(1));
     host_valid_ = false;
 }
 
@@ -224,8 +259,7 @@ void DiffusionGraph::diffusion(std::size_t first_iteration, std::size_t number_o
         // Nothing to print between iterations: run them as one call (the library then keeps
         // one colour on chip throughout) and log the mean time once per iteration.
         const auto t0 = std::chrono::steady_clock::now();
-        check(raster_order ? ds_iterate_raster(h_, (int)number_of_iterations)
-                           : ds_iterate(h_, (int)number_of_iterations));
+        check(iterate((int)number_of_iterations));
         const std::chrono::duration<double> dt = std::chrono::steady_clock::now() - t0;
         for (std::size_t i = 0; i < number_of_iterations; ++i) file << dt.count() / (double)number_of_iterations << "s";
         host_valid_ = false;
@@ -234,7 +268,7 @@ void DiffusionGraph::diffusion(std::size_t first_iteration, std::size_t number_o
     for (std::size_t i = first_iteration; i < first_iteration + number_of_iterations; ++i) {
         if (verbose) std::printf("Iteration # %zu\n", i);
         const auto t0 = std::chrono::steady_clock::now();
-        check(raster_order ? ds_iterate_raster(h_, 1) : ds_iterate(h_, 1));
+        check(iterate(1));
         const std::chrono::duration<double> dt = std::chrono::steady_clock::now() - t0;
         file << dt.count() << "s";
         if (verbose) std::printf("Energy: %.17g\n", energy());
@@ -246,7 +280,7 @@ double DiffusionGraph::energy()
 {
     push();
     double e = 0.;
-    check(ds_energy(h_, &e, nullptr));
+    check(banded_ ? ds_band_energy(h_, &e, nullptr) : ds_energy(h_, &e, nullptr));
     return e;
 }
 
@@ -260,6 +294,7 @@ static Matrix labels_to_matrix(const std::vector<std::uint32_t> &lab, std::size_
 
 Matrix DiffusionGraph::depth_map()
 {
+    whole_image_only("this operation");
     push();
     std::vector<std::uint32_t> lab(H_ * W_);
     check(ds_labels(h_, 1, lab.data()));
@@ -268,6 +303,7 @@ Matrix DiffusionGraph::depth_map()
 
 Matrix DiffusionGraph::belief_depth_map()
 {
+    whole_image_only("this operation");
     push();
     std::vector<std::uint32_t> lab(H_ * W_);
     check(ds_labels(h_, 0, lab.data()));
@@ -277,15 +313,17 @@ Matrix DiffusionGraph::belief_depth_map()
 bool DiffusionGraph::crossing_out_on_device(double epsilon, std::vector<std::uint8_t> &vertices, int *passes)
 {
     push();
-    vertices.assign(H_ * W_ * max_disparity, 0);
+    vertices.assign(rows_ * W_ * max_disparity, 0);
     int not_empty = 0, n = 0;
-    check(ds_crossing_out(h_, epsilon, 1 << 30, nullptr, vertices.data(), &not_empty, &n));
+    check(banded_ ? ds_band_crossing_out(h_, epsilon, 1 << 30, nullptr, vertices.data(), &not_empty, &n)
+                  : ds_crossing_out(h_, epsilon, 1 << 30, nullptr, vertices.data(), &not_empty, &n));
     if (passes) *passes = n;
     return not_empty != 0;
 }
 
 Matrix DiffusionGraph::find_best_labeling_on_device(bool &not_empty)
 {
+    whole_image_only("this operation");
     push();
     std::vector<std::uint32_t> flat(H_ * W_);
     int ok = 0;
@@ -299,6 +337,7 @@ Matrix DiffusionGraph::find_best_labeling_on_device(bool &not_empty)
 
 std::vector<double> DiffusionGraph::epsilon_gaps_on_device(bool &largest_repeated)
 {
+    whole_image_only("this operation");
     push();
     std::size_t count = 0;
     int repeated = 0;

@@ -26,6 +26,19 @@ public:
     static DiffusionGraph initialize(const std::vector<std::vector<std::uint32_t>> &left_image,
                                      const std::vector<std::vector<std::uint32_t>> &right_image,
                                      std::size_t max_disparity, double smoothing_term, int dtype = DS_F64);
+    // The same for the band [row_begin, row_end) of the image on HIP device `device`: one of
+    // several processes, one per GPU (the reference has one process; ds_create_band).  Only the
+    // device operations work on a band -- diffusion, energy, crossing_out_on_device -- and they
+    // run over all bands once attach() has said how the halo rows travel.
+    static DiffusionGraph initialize_band(const std::vector<std::vector<std::uint32_t>> &left_image,
+                                          const std::vector<std::vector<std::uint32_t>> &right_image,
+                                          std::size_t max_disparity, double smoothing_term, int dtype,
+                                          std::size_t row_begin, std::size_t row_end, int device);
+    void attach(ds_comm *comm, int up_rank, int down_rank);              // the library's RCCL transport
+    void attach(const ds_transport &transport, int up_rank, int down_rank);
+    bool banded() const { return banded_; }
+    std::size_t rows() const { return rows_; }            // rows this process owns (= height() unless banded)
+    std::size_t row_begin() const { return row_begin_; }
     DiffusionGraph(DiffusionGraph &&o) noexcept;
     DiffusionGraph &operator=(DiffusionGraph &&o) noexcept;
     DiffusionGraph(const DiffusionGraph &) = delete;
@@ -78,6 +91,7 @@ public:
 private:
     DiffusionGraph() = default;
     void check(int rc) const;
+    int iterate(int n);  // n iterations in the chosen order, over all bands if banded
     void pull();   // device -> host copy of phi, if stale
     void push();   // host copy -> device, if modified
     std::size_t idx(std::size_t i, std::size_t j, std::size_t n, std::size_t d) const
@@ -93,6 +107,12 @@ private:
     ds_handle *h_ = nullptr;
     int dtype_ = DS_F64;
     std::size_t H_ = 0, W_ = 0;
+    std::size_t row_begin_ = 0, rows_ = 0;
+    bool banded_ = false;
+    void whole_image_only(const char *what) const
+    {
+        if (banded_) throw std::logic_error(std::string(what) + " needs the whole image in one process");
+    }
     std::vector<double> phi_;  // host copy, reference layout
     bool host_valid_ = false, host_dirty_ = false;
 };

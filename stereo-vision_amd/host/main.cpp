@@ -7,6 +7,15 @@
 //                [--decode crossing|crossing-host|belief|epsilon-search] [--iterations K]
 //                [--tolerance T]
 //                [--schedule red-black|raster] [--labeling simple|best] [--quiet]
+//                [--gpus N] [--transport rccl|host] [--share-gpu]
+//
+// --gpus N splits the image into N row bands, one process per GPU (forked before anything
+// touches a GPU); the library runs the band protocol (ds_band_iterate, ds_band_energy,
+// ds_band_crossing_out) with its halo rows over RCCL, rank 0 gathers the labels and writes the
+// PGM.  --transport host moves the halo rows through host memory and sockets instead;
+// --share-gpu puts all ranks on device 0 (a rehearsal on a one-GPU machine; needs --transport
+// host, RCCL refuses two ranks on one device).  Bands decode with --decode crossing (default)
+// and --labeling simple, as the reference's main does.
 //
 // --decode crossing (default) is the reference pipeline: diffusion batches on the GPU
 // until the epsilon-consistent sub-graph is non-empty (crossing out on the GPU too), then
@@ -28,10 +37,69 @@
 #include <exception>
 #include <string>
 
+#include <unistd.h>
+
 #include "crossing_out_graph.hpp"
 #include "diffusion_graph.hpp"
 #include "epsilon_search.hpp"
 #include "pgm.hpp"
+#include "rank_group.hpp"
+
+namespace {
+
+// main over `world` row bands; every rank runs it, rank 0 returns the whole map.
+stereo::Matrix run_bands(stereo::RankGroup &group, const stereo::PgmImage &left, const stereo::PgmImage &right,
+                         std::size_t max_disparity, double smoothing, int dtype, double epsilon, std::size_t batch,
+                         std::size_t max_batches, bool verbose, bool rccl, bool share_gpu)
+{
+    using namespace stereo;
+    const int rank = group.rank(), world = group.world();
+    const std::size_t H = left.height;
+    if ((std::size_t)world > H) throw std::runtime_error("more bands than image rows");
+    const std::size_t base = H / world, extra = H % world;
+    const std::size_t rb = rank * base + std::min<std::size_t>(rank, extra), re = rb + base + ((std::size_t)rank < extra ? 1 : 0);
+    const int device = share_gpu ? 0 : rank;
+    DiffusionGraph graph = DiffusionGraph::initialize_band(left.matrix, right.matrix, max_disparity, smoothing, dtype,
+                                                           rb, re, device);
+    ds_comm *comm = nullptr;
+    ds_transport host{};
+    if (rccl) {
+        std::uint8_t id[DS_COMM_ID_BYTES] = {0};
+        int ok = rank != 0 || ds_comm_unique_id(id) == DS_OK;
+        group.broadcast(&ok, sizeof ok);
+        if (!ok) throw std::runtime_error(std::string("RCCL: ") + ds_comm_last_error(nullptr));
+        group.broadcast(id, sizeof id);
+        if (ds_comm_create(id, rank, world, device, &comm) != DS_OK)
+            throw std::runtime_error(std::string("RCCL: ") + ds_comm_last_error(nullptr));
+        graph.attach(comm, group.up(), group.down());
+    } else {
+        host = group.host_transport();
+        graph.attach(host, group.up(), group.down());
+    }
+    Matrix whole;
+    {
+        CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph), true);
+        // the same `verbose` on every rank: the energies it prints are collectives
+        cog.diffusion_while_not_consistent(epsilon, batch, max_batches, verbose);
+        const Matrix mine = cog.simple_best_labeling();
+        std::vector<std::uint32_t> flat;
+        for (const auto &row : mine)
+            for (std::size_t v : row) flat.push_back((std::uint32_t)v);
+        const auto parts = group.gather(flat.data(), flat.size() * sizeof(std::uint32_t));
+        if (rank == 0) {
+            for (const auto &part : parts) {
+                const std::uint32_t *v = reinterpret_cast<const std::uint32_t *>(part.data());
+                const std::size_t rows = part.size() / sizeof(std::uint32_t) / left.width;
+                for (std::size_t i = 0; i < rows; ++i) whole.emplace_back(v + i * left.width, v + (i + 1) * left.width);
+            }
+            if (whole.size() != H) throw std::runtime_error("gathered labels do not cover the image");
+        }
+    }  // the handle goes before the communicator it uses
+    ds_comm_destroy(comm);
+    return whole;
+}
+
+}  // namespace
 
 int main(int argc, char **argv)
 {
@@ -45,6 +113,8 @@ int main(int argc, char **argv)
     double smoothing = 1.2, epsilon = -1., tolerance = 1e-9;
     int dtype = DS_F64;
     bool crossing = true, host_masks = false, verbose = true, raster = false, search = false, best = false;
+    int gpus = 1;
+    bool rccl = true, share_gpu = false;
     for (int a = 4; a < argc; ++a) {
         const std::string o = argv[a];
         auto need = [&](const char *name) -> const char * {
@@ -89,10 +159,57 @@ int main(int argc, char **argv)
             best = mode == "best";
         }
         else if (o == "--quiet") verbose = false;
+        else if (o == "--gpus") gpus = std::atoi(need("--gpus"));
+        else if (o == "--share-gpu") share_gpu = true;
+        else if (o == "--transport") {
+            const std::string mode = need("--transport");
+            if (mode != "rccl" && mode != "host") {
+                std::fprintf(stderr, "unknown --transport %s\n", mode.c_str());
+                return 2;
+            }
+            rccl = mode == "rccl";
+        }
         else {
             std::fprintf(stderr, "unknown option %s\n", o.c_str());
             return 2;
         }
+    }
+    if (gpus < 1 || (gpus > 1 && (!crossing || host_masks || search || best || raster)) || (share_gpu && rccl && gpus > 1)) {
+        std::fprintf(stderr, "--gpus N needs --decode crossing, --labeling simple, --schedule red-black; "
+                             "--share-gpu needs --transport host\n");
+        return 2;
+    }
+    if (gpus > 1) {
+        int status = 1;
+        try {
+            RankGroup group = RankGroup::fork_ranks(gpus);  // before the first HIP call
+            // every rank runs the same code, prints included; only rank 0's reach the terminal
+            if (group.rank() != 0 && !std::freopen("/dev/null", "w", stdout)) _exit(1);
+            try {
+                const PgmImage right = pgm_reader(right_path);
+                const PgmImage left = pgm_reader(left_path);
+                if (right.width != left.width || right.height != left.height)
+                    throw std::runtime_error("left and right images differ in size");
+                if (epsilon < 0.) epsilon = 1. / double(10 * left.width * left.height);
+                if (group.rank() == 0) std::printf("Epsilon: %g\n", epsilon);
+                const Matrix map = run_bands(group, left, right, max_disparity, smoothing, dtype, epsilon, batch,
+                                             max_batches, verbose, rccl, share_gpu);
+                status = 0;
+                if (group.rank() == 0) {
+                    std::printf("Disparity map is consistent: %s\n", check_disparity_map(map) ? "true" : "false");
+                    pgm_writer(map, out_path, max_disparity);
+                    std::printf("Disparity map is saved to `%s`\n", out_path.c_str());
+                }
+            } catch (const std::exception &e) {
+                std::fprintf(stderr, "error (rank %d): %s\n", group.rank(), e.what());
+            }
+            std::fflush(stdout);
+            if (group.rank() != 0) _exit(status);  // children: no atexit handlers of the parent's state
+            status |= group.wait_children();
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "error: %s\n", e.what());
+        }
+        return status;
     }
     try {
         const PgmImage right = pgm_reader(right_path);

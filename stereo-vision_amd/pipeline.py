@@ -6,8 +6,11 @@ diffusion batches until the epsilon-consistent sub-graph is non-empty
 (crossing_out_graph.rs:254-275), then the smallest surviving label per pixel (:318-327).
 
 One process per GPU.  Started by torch.distributed.run the ranks split the image into
-row bands (bands.BandRunner: halo exchange per colour, crossing-out with mask halos and
-OR-ed flags); started plainly it is the single-GPU pipeline.
+row bands and the library runs the band protocol itself (ds_band_iterate, ds_band_energy,
+ds_band_crossing_out: halo rows over RCCL, crossing-out with mask halos and reduced flags);
+torch.distributed only carries the communicator's id and gathers the labels.  --backend gloo
+moves the halo rows through host memory instead (ranks sharing one GPU).  Started plainly it
+is the single-GPU pipeline.
 
     python stereo-vision_amd/pipeline.py LEFT.pgm RIGHT.pgm OUT.pgm [--max-disparity N]
         [--smoothing X] [--epsilon E] [--batch B] [--max-batches M] [--dtype f64|f32]
@@ -73,12 +76,13 @@ def diffusion_while_not_consistent(runner, epsilon, batch_size, max_batches=1000
 
 
 def run(left, right, max_disparity=40, smoothing=1.2, epsilon=None, batch=200, max_batches=1000,
-        dtype="f64", log=None, labeling="simple"):
+        dtype="f64", log=None, labeling="simple", transport=None):
     """The pipeline on already loaded images.  Uses the default process group if one is
     initialised (one band per rank), else a single band.  Returns (disparity map [H][W] on
     rank 0, None elsewhere; iterations done).  labeling: "simple" = simple_best_labeling
     (crossing_out_graph.rs:318-327, what the reference's main uses), "best" = find_best_labeling
-    (:349-364; sequential over the whole image, so one band only)."""
+    (:349-364; sequential over the whole image, so one band only).  transport: "rccl" (the
+    library's own) or "gloo" (through host memory); default: by the process group's backend."""
     import torch
     import torch.distributed as dist
     from . import bands, diffstereo
@@ -95,8 +99,11 @@ def run(left, right, max_disparity=40, smoothing=1.2, epsilon=None, batch=200, m
     rb, re = bands.partition_rows(H, world)[rank]
     graph = diffstereo.DiffusionGraph(left.astype(np.uint8), right.astype(np.uint8), max_disparity, smoothing,
                                       dtype=dtype, row_begin=rb, row_end=re, device=torch.cuda.current_device())
-    staged = multi and dist.get_backend() != "nccl"
-    runner = bands.BandRunner(bands.HipBandEngine(graph, stage_through_host=staged), rank=rank, world=world)
+    if transport is None:
+        transport = "rccl" if multi and dist.get_backend() == "nccl" else "gloo"
+    link = (bands.RcclComm(rank, world, torch.cuda.current_device()) if multi and transport == "rccl"
+            else bands.GlooTransport())
+    runner = bands.Bands(graph, link, rank, world)
     try:
         iters, result = diffusion_while_not_consistent(runner, epsilon, batch, max_batches,
                                                        log if rank == 0 else None)
@@ -113,6 +120,7 @@ def run(left, right, max_disparity=40, smoothing=1.2, epsilon=None, batch=200, m
         return (np.concatenate(parts, axis=0) if rank == 0 else None), iters
     finally:
         graph.close()
+        link.close()
 
 
 def main(argv=None):
@@ -136,7 +144,8 @@ def main(argv=None):
     if world > 1:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(a.backend)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("gloo")  # control plane; --backend chooses how halo rows travel
     rank = dist.get_rank() if world > 1 else 0
     try:
         right, _ = pgm_reader(a.right)
@@ -145,7 +154,7 @@ def main(argv=None):
             raise ValueError("left and right images differ in size")
         log = None if a.quiet else (lambda s: print(s, flush=True))
         labels, _ = run(left, right, a.max_disparity, a.smoothing, a.epsilon, a.batch, a.max_batches,
-                        a.dtype, log, a.labeling)
+                        a.dtype, log, a.labeling, "rccl" if a.backend == "nccl" else "gloo")
         if rank == 0:
             print("Disparity map is consistent: %s" % ("true" if check_disparity_map(labels) else "false"))
             pgm_writer(labels, a.out, a.max_disparity)
