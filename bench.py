@@ -168,7 +168,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # gloo is the control plane only (the communicator's id, barriers, the max over ranks);
         # the halo rows travel over RCCL inside the library
-        dist.init_process_group("gloo")
+        # (gloo reports its connections on stdout: keep that away from the one JSON line)
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     def all_agree(ok):
         t = torch.tensor([1 if ok else 0], dtype=torch.int32)
