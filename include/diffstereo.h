@@ -176,7 +176,11 @@ int ds_labels(ds_handle *h, int mode, uint32_t *out);
  * re-evaluated in whole-image passes until nothing changes (at most max_passes, else
  * DS_ERR_STATE).  labels: [H][W], 0xffffffff where a pixel lost every label; alive_out
  * (optional): [H][W][D] bytes, the reference's `vertices`; *not_empty = is_not_empty();
- * *passes = relaxation passes run.  Whole-image handles only. */
+ * *passes = relaxation passes run.  Whole-image handles only.
+ * The comparisons run in the handle's precision.  On an f32 handle an epsilon below
+ * 2^-23 * (255 + lambda * (D - 1)) -- the spacing of f32 numbers at the size the potentials
+ * reach -- is DS_ERR_ARG (ds_co_begin likewise): the reference's own default, 1 / (10 W H),
+ * needs an f64 handle from about 50 x 50 pixels on. */
 int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
                     int *not_empty, int *passes);
 
@@ -346,6 +350,18 @@ int ds_profile_split(ds_handle *h, int *n_half_sweeps, double *half_sweep_ms, in
 
 /* Geometry of the handle (any pointer may be NULL). */
 int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_begin, int *row_end);
+
+/* Replaces DiffusionGraph::box_blur (diffusion_stereo/src/diffusion_graph.rs:399-424), the
+ * post-filter of a disparity map (unused by the reference's main).  disparity_map: [H][W] on the
+ * host; out: [H][W] of 64-bit values (the reference's usize).  The arithmetic is that of a
+ * release build of the crate, where usize subtraction wraps: the window is rows [i - r, i + r) x
+ * columns [j - r, j + r) and is empty for i < r or j < r (such pixels keep value * 255 /
+ * normalization_term); a neighbour counts iff centre <= value <= centre + threshold; out =
+ * (centre + sum of counted values) * 255 / ((1 + count) * normalization_term), integer division.
+ * (A debug build of the crate panics on those subtractions instead.)  normalization_term = 0 is
+ * DS_ERR_ARG (the crate divides by it).  Whole-image handles only. */
+int ds_box_blur(ds_handle *h, const uint32_t *disparity_map, uint64_t threshold, uint64_t filter_radius,
+                uint64_t normalization_term, uint64_t *out);
 
 /* How phi was placed in HBM at creation.  For large problems the library allocates phi in
  * two plane groups and probes a few placements of the second group (timed sweeps), because

@@ -112,6 +112,39 @@ void og_cost_volume(const uint8_t *L, const uint8_t *R, int H, int W, int D, uin
  * line 3 = maxval, rest = whitespace separated integers (i32 cast to u32).
  * Two-call protocol: call with out == NULL to get W, H; then with a buffer of
  * W*H entries.  Returns 0, or -1 where the reference panics. */
+/* diffusion_graph.rs:399-424 (box_blur), with the arithmetic of a release build: usize
+ * subtraction wraps instead of panicking.  Consequences, restated literally:
+ *  - the window is rows [i - r, i + r) x columns [j - r, j + r); for i < r (or j < r) the
+ *    start wraps to a huge value, the range is empty and the pixel keeps only its own value;
+ *  - a neighbour smaller than the centre gives a wrapped (huge) difference, i.e. "> threshold":
+ *    only neighbours with centre <= value <= centre + threshold are averaged;
+ *  - up starts at the centre's value, down at 1; result = up * 255 / (down * norm), integer
+ *    division (the f64 round() of an integer changes nothing).
+ * A debug build panics in the first two cases; that is not restated.  norm == 0 -> returns 1. */
+int og_box_blur(const uint32_t *map, int H, int W, uint64_t threshold, uint64_t radius, uint64_t norm,
+                uint64_t *out)
+{
+    if (norm == 0) return 1;
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            const uint64_t centre = map[(size_t)i * W + j];
+            uint64_t up = centre, down = 1;
+            const uint64_t i_lo = (uint64_t)i - radius, i_hi = (uint64_t)i + radius;  /* wraps */
+            const uint64_t j_lo = (uint64_t)j - radius, j_hi = (uint64_t)j + radius;
+            for (uint64_t n_i = i_lo; n_i < i_hi; ++n_i)
+                for (uint64_t n_j = j_lo; n_j < j_hi; ++n_j)
+                    if (n_i < (uint64_t)H && n_j < (uint64_t)W) {
+                        const uint64_t v = map[n_i * (uint64_t)W + n_j];
+                        uint64_t filter_value = 1;
+                        if ((double)(v - centre) > (double)threshold) filter_value = 0;  /* wraps when v < centre */
+                        up += v * filter_value;
+                        down += filter_value;
+                    }
+            out[(size_t)i * W + j] = up * 255 / (down * norm);
+        }
+    return 0;
+}
+
 int og_pgm_reader(const char *path, uint32_t *out, int *W, int *H, int *maxval)
 {
     FILE *f = fopen(path, "r");

@@ -110,6 +110,7 @@ def lib():
         L.og_dedup_f64.argtypes = [P, I, C.c_double, P]
         L.og_cost_volume.argtypes = [P, P, I, I, I, P]
         L.og_cost_volume.restype = None
+        L.og_box_blur.argtypes = [P, I, I, C.c_uint64, C.c_uint64, C.c_uint64, P]
         L.og_pgm_reader.argtypes = [C.c_char_p, P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.og_pgm_writer.argtypes = [P, I, I, C.c_char_p, I]
         _LIB = L
@@ -163,6 +164,15 @@ def cost_volume(left, right, D):
     H, W = left.shape
     out = np.empty((D, H, W), dtype=np.uint8)
     lib().og_cost_volume(_ptr(left), _ptr(right), H, W, D, _ptr(out))
+    return out
+
+
+def box_blur(disparity_map, threshold, filter_radius, normalization_term):
+    """diffusion_graph.rs:399-424 with a release build's wrapping usize arithmetic.  u64 [H][W]."""
+    m = np.ascontiguousarray(disparity_map, dtype=np.uint32)
+    out = np.empty(m.shape, dtype=np.uint64)
+    if lib().og_box_blur(_ptr(m), m.shape[0], m.shape[1], threshold, filter_radius, normalization_term, _ptr(out)) != 0:
+        raise ZeroDivisionError("normalization_term is 0 (the reference divides by it)")
     return out
 
 

@@ -1167,6 +1167,17 @@ int ds_co_begin(ds_handle *h, double epsilon)
     if (!h) return DS_ERR_ARG;
     if (!(epsilon >= 0.0)) return fail(h, DS_ERR_ARG, "epsilon must be >= 0");
     const ds::Geometry &g = h->g;
+    if (h->dtype == DS_F32) {
+        // Vertices and edges are compared in the handle's precision.  An epsilon below the spacing of
+        // f32 numbers at the size the potentials reach (costs up to 255 plus lambda * (D - 1)) cannot
+        // be resolved: the masks would hang on rounding noise.  Such a run belongs on an f64 handle.
+        const double reach = 255.0 + std::fabs(h->lambda) * (g.D - 1);
+        const double resolution = reach * 1.1920928955078125e-07;  // 2^-23
+        if (epsilon < resolution)
+            return fail(h, DS_ERR_ARG,
+                        "epsilon " + std::to_string(epsilon) + " is below what f32 potentials resolve here (" +
+                            std::to_string(resolution) + "): use an f64 handle");
+    }
     int rc = need_current(h, "ds_co_begin");
     if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
@@ -1503,6 +1514,37 @@ int ds_dedup_gaps(const double *sorted, size_t n, double tolerance, int largest_
     if (n && (run_start != n - 1 || largest_repeated)) out[kept++] = sorted[n - 1];
     *n_out = kept;
     return DS_OK;
+}
+
+int ds_box_blur(ds_handle *h, const uint32_t *disparity_map, uint64_t threshold, uint64_t filter_radius,
+                uint64_t normalization_term, uint64_t *out)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!disparity_map || !out) return fail(h, DS_ERR_ARG, "disparity_map / out is NULL");
+    if (normalization_term == 0) return fail(h, DS_ERR_ARG, "normalization_term is 0 (the reference divides by it)");
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_box_blur needs the whole image");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    const size_t n = (size_t)g.H * g.W;
+    // the label buffer of ds_labels holds the input; the output (u64 like the reference's usize) is temporary
+    unsigned long long *d_out = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_out), n * sizeof(unsigned long long));
+    if (e != hipSuccess) return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP, std::string("hipMalloc(box blur): ") + hipGetErrorString(e));
+    auto done = [&](int code) {
+        (void)hipFree(d_out);
+        return code;
+    };
+    e = hipMemcpyAsync(h->d_labels, disparity_map, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return done(fail_hip(h, "hipMemcpyAsync(disparity map)", e));
+    hipLaunchKernelGGL(ds::box_blur_kernel, dim3((unsigned)((n + ds::kBlock - 1) / ds::kBlock)), dim3(ds::kBlock), 0,
+                       h->stream, h->d_labels, g.H, g.W, (unsigned long long)threshold, (unsigned long long)filter_radius,
+                       (unsigned long long)normalization_term, d_out);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return done(fail_hip(h, "box blur", e));
+    return done(DS_OK);
 }
 
 int ds_placement_info(const ds_handle *h, int *tries, double *probe_ms, int *split)

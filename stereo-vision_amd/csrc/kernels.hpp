@@ -1482,6 +1482,38 @@ __global__ __launch_bounds__(kBlock) void pack_cost_kernel(Geometry g, const uin
     }
 }
 
+// ---- post-filter of a disparity map -------------------------------------------------------
+// Reference: diffusion_stereo/src/diffusion_graph.rs:399-424 (box_blur), with the wrapping
+// usize arithmetic of a release build: the window is rows [i - r, i + r) x columns [j - r,
+// j + r) and is EMPTY when i < r or j < r (the range's start wraps past its end); a neighbour
+// smaller than the centre gives a wrapped, huge difference and never counts; up starts at the
+// centre's value and down at 1; out = up * 255 / (down * norm) in integer arithmetic.
+// One thread per pixel, lanes along j (the window's rows are read as coalesced runs).
+__global__ __launch_bounds__(kBlock) void box_blur_kernel(const uint32_t *__restrict__ map, int H, int W,
+                                                          unsigned long long threshold, unsigned long long radius,
+                                                          unsigned long long norm,
+                                                          unsigned long long *__restrict__ out)
+{
+    const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= (long long)H * W) return;
+    const int i = (int)(idx / W), j = (int)(idx % W);
+    const unsigned long long centre = map[idx];
+    unsigned long long up = centre, down = 1;
+    if ((unsigned long long)i >= radius && (unsigned long long)j >= radius) {
+        const unsigned long long i_hi = (unsigned long long)i + radius < (unsigned long long)H ? i + radius : H;
+        const unsigned long long j_hi = (unsigned long long)j + radius < (unsigned long long)W ? j + radius : W;
+        for (unsigned long long n_i = i - radius; n_i < i_hi; ++n_i)
+            for (unsigned long long n_j = j - radius; n_j < j_hi; ++n_j) {
+                const unsigned long long v = map[n_i * W + n_j];
+                // (v - centre) as f64 > threshold as f64, v - centre wrapping when v < centre
+                const bool keep = !((double)(v - centre) > (double)threshold);
+                up += keep ? v : 0ull;
+                down += keep ? 1ull : 0ull;
+            }
+    }
+    out[idx] = up * 255ull / (down * norm);
+}
+
 // ---- state initialisation / conversion -----------------------------------------------
 // phi <- 0 on labels d <= j, +inf elsewhere, for every row of the buffer (halo included).
 template <typename T>

@@ -69,6 +69,7 @@ SYMBOLS = {
     "ds_profile_end": (_I, [_P, _IP, _DP, _DP, _DP]),
     "ds_profile_split": (_I, [_P, _IP, _DP, _IP, _DP]),
     "ds_info": (_I, [_P, _IP, _IP, _IP, _IP, _IP, _IP]),
+    "ds_box_blur": (_I, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "ds_placement_info": (_I, [_P, _IP, _DP, _IP]),
     "ds_checksum": (_I, [_P, C.POINTER(C.c_uint64)]),
 }
@@ -353,6 +354,15 @@ class DiffusionGraph:
         n0, t0, n1, t1 = C.c_int(), C.c_double(), C.c_int(), C.c_double()
         self._chk(lib().ds_profile_split(self._h, C.byref(n0), C.byref(t0), C.byref(n1), C.byref(t1)))
         return {"half_sweeps": n0.value, "half_sweep_ms": t0.value, "fused": n1.value, "fused_ms": t1.value}
+
+    def box_blur(self, disparity_map, threshold, filter_radius, normalization_term):
+        """DiffusionGraph::box_blur (diffusion_graph.rs:399-424), release-build arithmetic.  u64 [H][W]."""
+        m = np.ascontiguousarray(disparity_map, dtype=np.uint32)
+        if m.shape != (self.H, self.W):
+            raise ValueError("disparity_map must have the image's shape")
+        out = np.empty(m.shape, dtype=np.uint64)
+        self._chk(lib().ds_box_blur(self._h, _ptr(m), int(threshold), int(filter_radius), int(normalization_term), _ptr(out)))
+        return out
 
     def placement_info(self):
         n, ms, sp = C.c_int(), C.c_double(), C.c_int()
