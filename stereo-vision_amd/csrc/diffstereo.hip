@@ -891,24 +891,35 @@ int ds_iterate(ds_handle *h, int n_iters)
     return DS_OK;
 }
 
-// All anti-diagonals of one raster-order iteration, in ascending i + j, on `stream`.
-static int launch_diagonals(ds_handle *h, hipStream_t stream)
+// n raster-order iterations as K + 2 (n - 1) dependent launches (see sweep_diagonals_kernel):
+// launch s carries diagonal s - 2 t of every iteration t that is live at that step.
+static int launch_raster(ds_handle *h, int n_iters)
 {
     const ds::Geometry &g = h->g;
+    const int K = g.H + g.W - 1;
     const int per_block = (ds::kBlock / 64) * (64 / h->lpp);  // pixels per block
-    for (int k = 0; k <= g.H + g.W - 2; ++k) {
-        const int i_begin = k - (g.W - 1) > 0 ? k - (g.W - 1) : 0;
-        const int i_end = k < g.H - 1 ? k : g.H - 1;  // inclusive
-        const int count = i_end - i_begin + 1;
-        const dim3 grid((count + per_block - 1) / per_block), block(ds::kBlock);
-        int rc = dispatch(h, [&](auto t, auto lpp) -> int {
-            using T = decltype(t);
-            hipLaunchKernelGGL((ds::sweep_diagonal_kernel<T, decltype(lpp)::value>), grid, block, 0, stream, g,
-                               static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, k, i_begin, count);
-            return DS_OK;
-        });
-        if (rc != DS_OK) return rc;
-        HIPCHK(h, hipGetLastError());
+    const int longest = g.H < g.W ? g.H : g.W;
+    const unsigned grid_x = (unsigned)((longest + per_block - 1) / per_block);
+    for (long long s = 0; s <= (long long)K - 1 + 2ll * (n_iters - 1); ++s) {
+        // live iterations: 0 <= s - 2 t <= K - 1 and 0 <= t < n
+        const long long lo = s - (K - 1) > 0 ? (s - (K - 1) + 1) / 2 : 0;
+        long long hi = s / 2;
+        if (hi > n_iters - 1) hi = n_iters - 1;
+        if (hi < lo) continue;
+        // at most 65535 iterations per launch (grid.y); the rest of the step in further launches,
+        // which are independent of one another
+        for (long long t0 = lo; t0 <= hi; t0 += 65535) {
+            const unsigned live = (unsigned)((hi - t0 + 1) < 65535 ? (hi - t0 + 1) : 65535);
+            const dim3 grid(grid_x, live), block(ds::kBlock);
+            int rc = dispatch(h, [&](auto t, auto lpp) -> int {
+                using T = decltype(t);
+                hipLaunchKernelGGL((ds::sweep_diagonals_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
+                                   static_cast<T *>(h->phi), h->cost_px, (T)h->lambda, (int)s, (int)t0);
+                return DS_OK;
+            });
+            if (rc != DS_OK) return rc;
+            HIPCHK(h, hipGetLastError());
+        }
     }
     return DS_OK;
 }
@@ -923,11 +934,13 @@ int ds_iterate_raster(ds_handle *h, int n_iters)
     int rc = need_current(h, "ds_iterate_raster");
     if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
-    // H + W - 1 dependent launches per iteration.  Replaying them from a recorded HIP graph
-    // was measured and changes nothing (35.3 vs 35.4 ms per iteration at 4K x 256): the cost
-    // is the GPU's kernel-to-kernel turnaround, not the host's launch calls.
-    for (int it = 0; it < n_iters; ++it) {
-        rc = launch_diagonals(h, h->stream);
+    // The launches of a step depend on the step before, so the cost is the GPU's kernel-to-kernel
+    // turnaround (replaying them from a recorded HIP graph was measured and changes nothing).  With
+    // n iterations in one call the steps number H + W - 1 + 2 (n - 1) instead of n (H + W - 1),
+    // and each carries up to n diagonals: the longer the call, the closer to the rate the update
+    // itself allows.
+    if (n_iters > 0) {
+        rc = launch_raster(h, n_iters);
         if (rc != DS_OK) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));

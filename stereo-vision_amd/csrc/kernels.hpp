@@ -562,23 +562,38 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Geometry g, T *__restrict
 // The reference's raster order (diffusion_graph.rs:264-269), exactly: pixel (i, j) reads its
 // left and top neighbours after their update of this iteration and its right and bottom
 // neighbours before theirs.  All four lie on the anti-diagonals i + j -+ 1, so the pixels of
-// one anti-diagonal k = i + j are independent of one another, and launching the diagonals in
-// increasing k reproduces the sequential sweep.  One launch = one diagonal: pixels
-// (i_begin + m, k - i_begin - m), m < count, all of colour k & 1.
+// one anti-diagonal k = i + j are independent of one another, and updating the diagonals in
+// increasing k reproduces the sequential sweep: pixels (i_begin + m, k - i_begin - m), all of
+// colour k & 1.
+//
+// Several raster-order iterations in flight at once.  Anti-diagonal k of iteration t needs
+// diagonal k - 1 of iteration t (its left / top neighbours, already updated) and diagonal k + 1
+// of iteration t - 1 (its right / bottom neighbours, not yet updated in t): both carry the
+// "time step" s - 1 where s = k + 2 t.  So all diagonals with the same s are independent, and a
+// call of n iterations needs K + 2 (n - 1) dependent launches (K = H + W - 1 diagonals) instead
+// of n K: launch s updates, in place, diagonal s - 2 t of iteration t for every t it is live in.
+// Pixels see exactly the operands of the sequential sweep, so the result is the same, bit for
+// bit, as one diagonal per launch.  grid.y = the live iterations (t = t_lo + blockIdx.y),
+// grid.x = pixel groups of the longest diagonal.
 template <typename T, int LPP>
-__global__ __launch_bounds__(kBlock) void sweep_diagonal_kernel(Geometry g, T *__restrict__ phi,
-                                                                const uint8_t *__restrict__ cost, T lambda,
-                                                                int k, int i_begin, int count)
+__global__ __launch_bounds__(kBlock) void sweep_diagonals_kernel(Geometry g, T *phi, const uint8_t *__restrict__ cost,
+                                                                 T lambda, int s, int t_lo)
 {
     constexpr int PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int k = s - 2 * (t_lo + (int)blockIdx.y);  // host guarantees 0 <= k <= H + W - 2
+    const int i_begin = k - (g.W - 1) > 0 ? k - (g.W - 1) : 0;
+    const int i_end = k < g.H - 1 ? k : g.H - 1;  // inclusive
+    const int count = i_end - i_begin + 1;
+    const int m0 = (blockIdx.x * (kBlock / 64) + wave) * PPW;
+    if (m0 >= count) return;  // whole wavefront beyond this diagonal
     T lam[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
     const int colour = k & 1;
     const uint8_t *cost_c = cost + colour * g.cost_colour_stride;
-    const int m = (blockIdx.x * (kBlock / 64) + wave) * PPW + q;
+    const int m = m0 + q;
     const bool in_range = m < count;
     const int i = in_range ? i_begin + m : i_begin;
     const int j = in_range ? k - i : 2 * g.Wh + 1;  // past the last column: locate() marks it inactive

@@ -69,6 +69,32 @@ def test_bundled_pair_100_sequential_iterations(golden_dir):
     g.close()
 
 
+@pytest.mark.parametrize("H,W,D,dtype,n", [(6, 9, 5, "f64", 7), (13, 4, 20, "f32", 5), (3, 40, 130, "f32", 4),
+                                           (1, 9, 3, "f64", 6), (9, 1, 3, "f64", 6), (24, 31, 64, "f64", 40)])
+def test_iterations_in_flight_equal_iterations_one_by_one(H, W, D, dtype, n):
+    """One call of n iterations keeps up to n of them in flight (diagonal k of iteration t beside
+    diagonal k + 2 of iteration t - 1, ...); every pixel still sees the sequential sweep's
+    operands, so the result equals n calls of one iteration bit for bit -- and the oracle."""
+    left, right = random_pair(H, W, seed=H + 5 * W + D)
+    phi0 = random_phi(H, W, D, dtype, seed=4)
+    a = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    b = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    a.set_phi(phi0)
+    b.set_phi(phi0)
+    a.iterate_raster(n)
+    for _ in range(n):
+        b.iterate_raster(1)
+    assert np.array_equal(a.get_phi(), b.get_phi())
+    if H * W * D * D * n <= 3_000_000:
+        o = OracleGraph(left, right, D, 1.2, dtype=dtype)
+        o.set_potentials(phi0)
+        for _ in range(n):
+            o.diffusion_act()
+        assert rel_err(a.get_phi(), o.potentials) <= TOL[dtype]
+    a.close()
+    b.close()
+
+
 def test_band_refusal():
     left, right = random_pair(4, 4)
     band = diffstereo.DiffusionGraph(left, right, 4, 1.2, row_begin=1, row_end=3)
