@@ -348,6 +348,22 @@ int ds_profile_end(ds_handle *h, int *n_launches, double *total_ms, double *min_
  * kernel (ds_iterate, ds_iterate_rows). */
 int ds_profile_split(ds_handle *h, int *n_half_sweeps, double *half_sweep_ms, int *n_fused, double *fused_ms);
 
+/* The same for one kind of launch: 0 = half-sweeps, 1 = one-iteration launches of the fused
+ * kernel, 2 = two-iteration launches (ds_fused2_info). */
+int ds_profile_kind(ds_handle *h, int kind, int *n_launches, double *ms);
+
+/* Two iterations per launch.  On whole-image f32 handles whose D fills the lanes (D = 64, 128 or
+ * 256) ds_iterate runs its iterations in pairs while more than two remain: one kernel computes
+ * both iterations on chip for the part of the image where nothing needs masking -- output
+ * columns [*col_begin, *col_end), rows [*row_begin, *row_end) -- and the frame around it goes
+ * through the one-iteration kernel twice, beside it on a second stream (a third set of
+ * second-colour planes, allocated on first use, holds the frame's middle state; without the
+ * memory for it, or with DS_FUSED2=off, every iteration is a launch of its own).  Same bits
+ * either way.  *available: the handle has such a part; *steps: two-iteration steps run so far.
+ * No counterpart in the reference.  Any pointer may be NULL. */
+int ds_fused2_info(const ds_handle *h, int *available, int *col_begin, int *col_end, int *row_begin, int *row_end,
+                   long long *steps);
+
 /* Geometry of the handle (any pointer may be NULL). */
 int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_begin, int *row_end);
 

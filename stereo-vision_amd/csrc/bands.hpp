@@ -159,24 +159,6 @@ int need_attached(ds_handle *h, const char *who)
     return DS_OK;
 }
 
-// Work queued on `from` so far happens before work queued on `to` from now on.
-int order(ds_handle *h, hipStream_t from, hipEvent_t ev, hipStream_t to)
-{
-    HIPCHK(h, hipEventRecord(ev, from));
-    HIPCHK(h, hipStreamWaitEvent(to, ev, 0));
-    return DS_OK;
-}
-
-// Launches of the library go to h->stream: run `body` with the boundary stream in its place.
-template <typename F> int on_side(ds_handle *h, F &&body)
-{
-    hipStream_t keep = h->stream;
-    h->stream = h->side_stream;
-    const int rc = body();
-    h->stream = keep;
-    return rc;
-}
-
 // Halo row of phi: device pointer and size (see ds_halo).  upcoming = the colour-1 planes the
 // running iteration is producing instead of the current ones.
 void halo_row(const ds_handle *h, int colour, bool upcoming, int side, int which, void **ptr, size_t *bytes)
@@ -217,10 +199,10 @@ int band_half_sweep(ds_handle *h, int colour)
     const int top_end = h->up >= 0 ? (rb + 1 < re ? rb + 1 : re) : rb;
     const int bot_begin = h->down >= 0 ? (re - 1 > top_end ? re - 1 : top_end) : re;
     int rc = launch_sweep(h, colour, rb, top_end, nullptr, bot_begin, re);
-    if (rc == DS_OK) rc = order(h, h->stream, h->ev_main, h->side_stream);
+    if (rc == DS_OK) rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
     if (rc == DS_OK) rc = exchange_phi(h, colour, false, h->side_stream);
     if (rc == DS_OK) rc = launch_sweep(h, colour, top_end, bot_begin);
-    if (rc == DS_OK) rc = order(h, h->side_stream, h->ev_side, h->stream);
+    if (rc == DS_OK) rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
     return rc;
 }
 
@@ -230,9 +212,9 @@ int band_fused_iteration(ds_handle *h, int fb, int fe)
 {
     const int rb = h->g.row0, re = h->g.row0 + h->g.Hb;
     // the chain reads what the previous interior kernel wrote, and writes the planes it read
-    int rc = order(h, h->stream, h->ev_main, h->side_stream);
+    int rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
     if (rc != DS_OK) return rc;
-    rc = on_side(h, [&]() -> int {
+    rc = on_side_stream(h, [&]() -> int {
         const int t0 = rb, t1 = h->up >= 0 ? rb + 2 : rb;      // first colour: two rows next to each neighbour
         const int b0 = h->down >= 0 ? re - 2 : re, b1 = re;
         int r = launch_sweep(h, 0, t0, t1, nullptr, b0, b1);
@@ -245,7 +227,7 @@ int band_fused_iteration(ds_handle *h, int fb, int fe)
         return r;
     });
     if (rc == DS_OK) rc = launch_fused(h, fb, fe);  // handle's stream; makes the produced planes current
-    if (rc == DS_OK) rc = order(h, h->side_stream, h->ev_side, h->stream);
+    if (rc == DS_OK) rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
     return rc;
 }
 
@@ -367,9 +349,8 @@ int ds_band_attach(ds_handle *h, const ds_transport *t, int up_rank, int down_ra
         return fail(h, DS_ERR_ARG, "a band has a neighbour above / below exactly where the image continues");
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
-    if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-    if (!h->ev_main) HIPCHK(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
-    if (!h->ev_side) HIPCHK(h, hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+    rc = need_side_stream(h);
+    if (rc != DS_OK) return rc;
     if (!h->d_flag) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->d_flag), sizeof(int));
         if (e != hipSuccess) return fail_hip(h, "hipMalloc(flag)", e);

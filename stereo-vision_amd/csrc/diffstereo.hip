@@ -64,6 +64,15 @@ struct ds_handle {
     void *phi_b = nullptr;        // group B when allocated apart, else NULL
     int fused_waves = 0;          // wavefronts per block of the fused kernel; 0 = not available
     bool fused_pending = false;   // fused launches since the first colour's planes were last current
+    // two iterations per launch (see plan_fused2): the interior's output columns [cL, cR) and
+    // rows [rT, rB), and a third set of colour-1 planes for the frame's first iteration
+    struct Fused2Plan {
+        bool ok = false;
+        int cL = 0, cR = 0, strips = 0, rT = 0, rB = 0, strip1 = 0, waves = 16;
+    } plan2;
+    void *phi_y = nullptr;
+    long long y_off[4] = {0, 0, 0, 0};
+    long long fused2_steps = 0;   // two-iteration steps run so far (ds_fused2_info)
     int cu_count = 256;
     long long alt_off[4] = {0, 0, 0, 0};
     std::vector<int> prof_kind;   // per timed launch: 0 = half-sweep, 1 = fused iteration
@@ -208,6 +217,7 @@ void release(ds_handle *h)
     (void)hipFree(h->cost_px);
     (void)hipFree(h->phi);
     (void)hipFree(h->phi_b);
+    (void)hipFree(h->phi_y);
     (void)hipFree(h->part_sum);
     (void)hipFree(h->part_max);
     (void)hipFree(h->d_scalars);
@@ -282,24 +292,22 @@ void fused_safe_rows(const ds_handle *h, int *begin, int *end)
     *end = g.row0 + g.Hb == g.H ? g.H : g.row0 + g.Hb - 1;
 }
 
-int launch_fused(ds_handle *h, int row_begin, int row_end)
+// The one-iteration kernel over the colour-1 rows [row_begin, row_end) and `strips` column
+// strips from column col_begin (even) on: reads the colour-1 planes `in_off`, writes `out_off`
+// (element offsets from the phi base).  kind: how the launch is booked by ds_profile_*.
+int launch_fused_region(ds_handle *h, const long long in_off[4], const long long out_off[4], int col_begin, int strips,
+                        int row_begin, int row_end, int kind)
 {
     const int rows = row_end - row_begin;
-    if (rows <= 0) return DS_OK;
-    ds::Geometry &g = h->g;
-    int safe_begin = 0, safe_end = 0;
-    fused_safe_rows(h, &safe_begin, &safe_end);
-    // Exactly the safe rows: the launch makes the other set of colour-1 planes current, so rows
-    // it leaves out would silently fall back to what that set held two iterations ago.
-    if (!h->fused_waves || row_begin != safe_begin || row_end != safe_end)
-        return fail(h, DS_ERR_ARG, "a fused iteration must cover exactly the rows ds_fused_rows reports");
+    if (rows <= 0 || strips <= 0) return DS_OK;
+    ds::Geometry geo = h->g;
+    for (int s = 0; s < 4; ++s) geo.plane_off[1][s] = in_off[s];
     const bool timed = h->prof && h->prof_n < h->prof_cap;
     if (timed) {
         HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
-        h->prof_kind[h->prof_n] = 1;
+        h->prof_kind[h->prof_n] = kind;
     }
-    const int fw = h->fused_waves, strip_cols = 2 * (fw * (64 / h->lpp) - 1);
-    const int strips = (g.W + strip_cols - 1) / strip_cols;
+    const int fw = h->fused_waves;
     // Row segments.  One or two blocks fill a CU's LDS, so the grid runs in rounds; many short
     // blocks even out the slower border strips and whatever CUs a concurrent transfer kernel
     // holds, and a segment only costs the two extra red rows it recomputes.  Measured with
@@ -318,20 +326,20 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
     const int rows_per_seg = (rows + segs - 1) / segs;
     const dim3 grid(strips, (rows + rows_per_seg - 1) / rows_per_seg), block(64 * fw);
     ds::FusedPlanes np;
-    for (int s = 0; s < 4; ++s) np.out_off[s] = h->alt_off[s];
+    for (int s = 0; s < 4; ++s) np.out_off[s] = out_off[s];
     int rc = dispatch(h, [&](auto t, auto lpp) -> int {
         using T = decltype(t);
         constexpr int L = decltype(lpp)::value;
         auto go = [&](auto fwc) {
             constexpr int FW = decltype(fwc)::value;
             if (h->probing)
-                hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, true>), grid, block, 0, h->stream, g,
+                hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, true>), grid, block, 0, h->stream, geo,
                                    static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end,
-                                   rows_per_seg);
+                                   rows_per_seg, col_begin);
             else
-                hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, false>), grid, block, 0, h->stream, g,
+                hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, false>), grid, block, 0, h->stream, geo,
                                    static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end,
-                                   rows_per_seg);
+                                   rows_per_seg, col_begin);
         };
         if (fw == 16) go(std::integral_constant<int, 16>{});
         else if (fw == 8) go(std::integral_constant<int, 8>{});
@@ -344,9 +352,196 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
         HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n + 1], h->stream));
         ++h->prof_n;
     }
+    return DS_OK;
+}
+
+// One whole iteration over the handle's fused rows, all columns: current colour-1 planes ->
+// the alternate set, which becomes current.
+int launch_fused(ds_handle *h, int row_begin, int row_end)
+{
+    if (row_end - row_begin <= 0) return DS_OK;
+    ds::Geometry &g = h->g;
+    int safe_begin = 0, safe_end = 0;
+    fused_safe_rows(h, &safe_begin, &safe_end);
+    // Exactly the safe rows: the launch makes the other set of colour-1 planes current, so rows
+    // it leaves out would silently fall back to what that set held two iterations ago.
+    if (!h->fused_waves || row_begin != safe_begin || row_end != safe_end)
+        return fail(h, DS_ERR_ARG, "a fused iteration must cover exactly the rows ds_fused_rows reports");
+    const int strip_cols = 2 * (h->fused_waves * (64 / h->lpp) - 1);
+    int rc = launch_fused_region(h, g.plane_off[1], h->alt_off, 0, (g.W + strip_cols - 1) / strip_cols, row_begin,
+                                 row_end, 1);
+    if (rc != DS_OK) return rc;
     for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
     h->fused_pending = true;
     return DS_OK;
+}
+
+// Work queued on `from` so far happens before work queued on `to` from now on.
+int order_streams(ds_handle *h, hipStream_t from, hipEvent_t ev, hipStream_t to)
+{
+    HIPCHK(h, hipEventRecord(ev, from));
+    HIPCHK(h, hipStreamWaitEvent(to, ev, 0));
+    return DS_OK;
+}
+
+// Launches of the library go to h->stream: run `body` with the side stream in its place.
+template <typename F> int on_side_stream(ds_handle *h, F &&body)
+{
+    hipStream_t keep = h->stream;
+    h->stream = h->side_stream;
+    const int rc = body();
+    h->stream = keep;
+    return rc;
+}
+
+// The second stream of a handle (a band's boundary rows, the borders of a two-iteration step)
+// and the two events that order it against the handle's stream.
+int need_side_stream(ds_handle *h)
+{
+    if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    if (!h->ev_main) HIPCHK(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    if (!h->ev_side) HIPCHK(h, hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+    return DS_OK;
+}
+
+// ---- two iterations per launch -------------------------------------------------------------
+// fused2_iteration_kernel takes the part of the image where nothing needs masking: output
+// columns [cL, cR) x rows [rT, rB).  The frame around it goes through the one-iteration kernel
+// twice, via a third set of colour-1 planes Y (allocated on first use): X -> Y on the frame
+// widened by two pixels (the second iteration of a frame pixel reads first-iteration values up
+// to two pixels away), then Y -> Z on the frame itself.  Z is also where the two-iteration
+// kernel writes, so after the step Z holds iteration n + 2 everywhere and becomes current.
+// The frame's eight launches run on the side stream beside the interior kernel: both read X
+// only (and Y, which nothing else touches) and write disjoint parts of Z.
+void plan_fused2(ds_handle *h)
+{
+    ds_handle::Fused2Plan &p = h->plan2;
+    p = ds_handle::Fused2Plan{};
+    const ds::Geometry &g = h->g;
+    const char *e = std::getenv("DS_FUSED2");
+    if (e && std::strcmp(e, "off") == 0) return;
+    if (h->dtype != DS_F32 || h->fused_waves != 16 || g.row0 != 0 || g.Hb != g.H || g.D != 4 * h->lpp) return;
+    p.waves = 16;
+    p.waves = 12;
+    if (const char *w = std::getenv("DS_F2_WAVES")) p.waves = std::atoi(w) == 16 ? 16 : 12;  // tuning knob
+    const int FC1 = 2 * (16 * (64 / h->lpp) - 1);                 // the one-iteration kernel's strip
+    const int NP = p.waves * (64 / h->lpp), FC2 = 2 * (NP - 3);   // the two-iteration kernel's slots and strip
+    p.cL = ((g.D + 3 + FC1 - 1) / FC1) * FC1;  // a multiple of the one-iteration strip; c0 - 1 = cL - 3 >= D
+    const long long room = (long long)g.W - 1 - 2 * NP - (p.cL - 2);  // c0 of the last strip + 2 NP < W
+    p.strips = room >= 0 ? (int)(room / FC2) + 1 : 0;
+    p.cR = p.cL + p.strips * FC2;
+    p.rT = 4;
+    p.rB = g.H - 4;
+    p.strip1 = FC1;
+    p.ok = p.strips >= 1 && p.rB - p.rT >= 8;
+}
+
+int fused2_step(ds_handle *h)
+{
+    ds::Geometry &g = h->g;
+    const ds_handle::Fused2Plan &p = h->plan2;
+    const long long *X = g.plane_off[1], *Y = h->y_off, *Z = h->alt_off;
+    const int all = (g.W + p.strip1 - 1) / p.strip1;  // one-iteration strips over the whole width
+    int rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
+    if (rc != DS_OK) return rc;
+    const bool skip_frame = std::getenv("DS_F2_SKIP_FRAME") != nullptr;  // timing experiments only: wrong results
+    rc = on_side_stream(h, [&]() -> int {
+        if (skip_frame) return DS_OK;
+        // first iteration on the widened frame: X -> Y
+        int r = launch_fused_region(h, X, Y, 0, all, 0, p.rT + 2, 1);
+        if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, all, p.rB - 2, g.H, 1);
+        if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2, 1);
+        if (r == DS_OK)
+            r = launch_fused_region(h, X, Y, p.cR - p.strip1, (g.W - (p.cR - p.strip1) + p.strip1 - 1) / p.strip1,
+                                    p.rT + 2, p.rB - 2, 1);
+        // second iteration on the frame: Y -> Z
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, 0, p.rT, 1);
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, p.rB, g.H, 1);
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, p.cL / p.strip1, p.rT, p.rB, 1);
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB, 1);
+        return r;
+    });
+    if (rc != DS_OK) return rc;
+    // the interior: X -> Z, both iterations on chip
+    const int rows = p.rB - p.rT;
+    int per_seg = 96;
+    if (const char *e = std::getenv("DS_FUSED2_ROWS")) per_seg = std::atoi(e) > 0 ? std::atoi(e) : per_seg;  // tuning knob
+    int segs = (rows + per_seg - 1) / per_seg;
+    const int rows_per_seg = (rows + segs - 1) / segs;
+    segs = (rows + rows_per_seg - 1) / rows_per_seg;
+    const bool timed = h->prof && h->prof_n < h->prof_cap;
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
+        h->prof_kind[h->prof_n] = 2;
+    }
+    ds::Geometry in = g;
+    ds::FusedPlanes np;
+    for (int s = 0; s < 4; ++s) np.out_off[s] = Z[s];
+    const dim3 grid(p.strips, segs), block(64 * p.waves);
+    float *base = static_cast<float *>(h->phi);
+    const float lambda = (float)h->lambda;
+    const char *vv = std::getenv("DS_F2_VARIANT");
+    const bool packed = !(vv && std::atoi(vv) == 3);
+    auto go = [&](auto lppc, auto wavesc) {
+        if (packed)
+            hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, decltype(lppc)::value, decltype(wavesc)::value, 7>), grid, block,
+                               0, h->stream, in, base, base, np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg);
+        else
+            hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, decltype(lppc)::value, decltype(wavesc)::value, 3>), grid, block,
+                               0, h->stream, in, base, base, np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg);
+    };
+    auto with_waves = [&](auto lppc) {
+        if (p.waves == 12) go(lppc, std::integral_constant<int, 12>{});
+        else go(lppc, std::integral_constant<int, 16>{});
+    };
+    switch (h->lpp) {
+    case 16: with_waves(std::integral_constant<int, 16>{}); break;
+    case 32: with_waves(std::integral_constant<int, 32>{}); break;
+    default: with_waves(std::integral_constant<int, 64>{}); break;
+    }
+    HIPCHK(h, hipGetLastError());
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n + 1], h->stream));
+        ++h->prof_n;
+    }
+    rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
+    if (rc != DS_OK) return rc;
+    for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
+    h->fused_pending = true;
+    return DS_OK;
+}
+
+// Y planes and the side stream, on first use.  Returns false (and switches the plan off) if the
+// memory is not there: the caller then iterates one iteration per launch.
+bool prepare_fused2(ds_handle *h)
+{
+    if (!h->plan2.ok) return false;
+    if (h->phi_y) return true;
+    if (need_side_stream(h) != DS_OK) {
+        h->plan2.ok = false;
+        return false;
+    }
+    const size_t bytes = (size_t)(4 * h->plane_elems) * h->elem;
+    if (hipMalloc(&h->phi_y, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        h->phi_y = nullptr;
+        h->plan2.ok = false;
+        return false;
+    }
+    const long long off = (static_cast<char *>(h->phi_y) - static_cast<char *>(h->phi)) / (long long)h->elem;
+    for (int s = 0; s < 4; ++s) h->y_off[s] = off + s * h->plane_elems;
+    // same +inf / 0 pattern as every other plane (the entries no kernel writes must hold +inf)
+    ds::Geometry y = h->g;
+    for (int s = 0; s < 4; ++s) y.plane_off[1][s] = h->y_off[s];
+    long long blocks = (8 * h->plane_elems + ds::kBlock - 1) / ds::kBlock;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ds::init_phi_kernel<float>, dim3((unsigned)blocks), dim3(ds::kBlock), 0, h->stream, y,
+                       static_cast<float *>(h->phi));
+    if (hipGetLastError() != hipSuccess) {
+        h->plan2.ok = false;
+        return false;
+    }
+    return true;
 }
 
 // After fused iterations the colour-0 planes are out of date: phi of colour 0 after iteration
@@ -643,6 +838,7 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     CREATE_HIPCHK(hipMalloc(&h->d_labels, (size_t)g.Hb * W * sizeof(uint32_t)));
 #undef CREATE_HIPCHK
 
+    plan_fused2(h);
     rc = build_cost(h);
     if (rc == DS_OK) rc = place_phi(h);
     if (rc == DS_OK) rc = init_phi(h);
@@ -874,7 +1070,19 @@ int ds_iterate(ds_handle *h, int n_iters)
     if (h->fused_waves && n_iters > 0) {
         // n whole iterations that move only the second colour's planes, then the first
         // colour's planes brought up to date: the same bits as 2n half-sweeps
-        for (int it = 0; it < n_iters; ++it) {
+        // Two iterations per launch while more than two remain: the last one always runs alone,
+        // because bringing the first colour up to date needs the second colour's planes of the
+        // iteration before the last, and a two-iteration step never stores its middle state.
+        int left = n_iters;
+        if (left >= 3 && prepare_fused2(h)) {
+            while (left >= 3) {
+                rc = fused2_step(h);
+                if (rc != DS_OK) return rc;
+                ++h->fused2_steps;
+                left -= 2;
+            }
+        }
+        for (int it = 0; it < left; ++it) {
             rc = launch_fused(h, 0, h->g.H);
             if (rc != DS_OK) return rc;
         }
@@ -888,6 +1096,7 @@ int ds_iterate(ds_handle *h, int n_iters)
             }
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->side_stream) HIPCHK(h, hipStreamSynchronize(h->side_stream));
     return DS_OK;
 }
 
@@ -1152,7 +1361,8 @@ int ds_profile_split(ds_handle *h, int *n_half_sweeps, double *half_sweep_ms, in
     for (int k = 0; k < h->prof_n; ++k) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->events[2 * k], h->events[2 * k + 1]));
-        const int kind = h->prof_kind[k] ? 1 : 0;
+        const int kind = h->prof_kind[k];
+        if (kind > 1) continue;  // two-iteration launches: ds_profile_kind(h, 2, ...)
         ++n[kind];
         t[kind] += ms;
     }
@@ -1160,6 +1370,40 @@ int ds_profile_split(ds_handle *h, int *n_half_sweeps, double *half_sweep_ms, in
     if (half_sweep_ms) *half_sweep_ms = t[0];
     if (n_fused) *n_fused = n[1];
     if (fused_ms) *fused_ms = t[1];
+    return DS_OK;
+}
+
+int ds_profile_kind(ds_handle *h, int kind, int *n_launches, double *ms)
+{
+    if (!h) return DS_ERR_ARG;
+    if (kind < 0 || kind > 2) return fail(h, DS_ERR_ARG, "kind must be 0, 1 or 2");
+    if (h->prof) return fail(h, DS_ERR_STATE, "ds_profile_kind before ds_profile_end");
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    int n = 0;
+    double t = 0;
+    for (int k = 0; k < h->prof_n; ++k) {
+        if (h->prof_kind[k] != kind) continue;
+        float one = 0;
+        HIPCHK(h, hipEventElapsedTime(&one, h->events[2 * k], h->events[2 * k + 1]));
+        ++n;
+        t += one;
+    }
+    if (n_launches) *n_launches = n;
+    if (ms) *ms = t;
+    return DS_OK;
+}
+
+int ds_fused2_info(const ds_handle *h, int *available, int *col_begin, int *col_end, int *row_begin, int *row_end,
+                   long long *steps)
+{
+    if (!h) return DS_ERR_ARG;
+    if (available) *available = h->plan2.ok ? 1 : 0;
+    if (col_begin) *col_begin = h->plan2.cL;
+    if (col_end) *col_end = h->plan2.cR;
+    if (row_begin) *row_begin = h->plan2.rT;
+    if (row_end) *row_end = h->plan2.rB;
+    if (steps) *steps = h->fused2_steps;
     return DS_OK;
 }
 

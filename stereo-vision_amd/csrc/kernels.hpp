@@ -643,7 +643,8 @@ template <typename T, int NP, int DL> struct FusedLds {
 template <typename T, int LPP, int FW, bool PROBE = false>
 __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
                                                                   const uint8_t *__restrict__ cost, T lambda,
-                                                                  int row_begin, int row_end, int rows_per_seg)
+                                                                  int row_begin, int row_end, int rows_per_seg,
+                                                                  int col_begin)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP, NP = FW * PPW, NB = NP - 1, FC = 2 * NB, DL = 4 * LPP;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
     T lam[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
-    const int c0 = blockIdx.x * FC;
+    const int c0 = col_begin + blockIdx.x * FC;  // col_begin even: strips may start anywhere (launches over a part of the image)
     const int a = c0 - 1 + 2 * kp;  // first column of the slot's pair (odd)
     const int r0 = row_begin + blockIdx.y * rows_per_seg;
     const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
@@ -1589,3 +1590,6 @@ __global__ __launch_bounds__(kBlock) void checksum_kernel(Geometry g, const T *_
 }
 
 }  // namespace ds
+
+#include <type_traits>
+#include "fused2.hpp"

@@ -68,6 +68,8 @@ SYMBOLS = {
     "ds_profile_begin": (_I, [_P, _I]),
     "ds_profile_end": (_I, [_P, _IP, _DP, _DP, _DP]),
     "ds_profile_split": (_I, [_P, _IP, _DP, _IP, _DP]),
+    "ds_profile_kind": (_I, [_P, _I, _IP, _DP]),
+    "ds_fused2_info": (_I, [_P, _IP, _IP, _IP, _IP, _IP, C.POINTER(C.c_longlong)]),
     "ds_info": (_I, [_P, _IP, _IP, _IP, _IP, _IP, _IP]),
     "ds_box_blur": (_I, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "ds_placement_info": (_I, [_P, _IP, _DP, _IP]),
@@ -363,6 +365,20 @@ class DiffusionGraph:
         out = np.empty(m.shape, dtype=np.uint64)
         self._chk(lib().ds_box_blur(self._h, _ptr(m), int(threshold), int(filter_radius), int(normalization_term), _ptr(out)))
         return out
+
+    def profile_kind(self, kind):
+        """After profile_end: (launches, milliseconds) of one kind: 0 half-sweeps, 1 one-iteration
+        fused launches, 2 two-iteration launches."""
+        n, ms = C.c_int(), C.c_double()
+        self._chk(lib().ds_profile_kind(self._h, int(kind), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def fused2_info(self):
+        v = [C.c_int() for _ in range(5)]
+        steps = C.c_longlong()
+        self._chk(lib().ds_fused2_info(self._h, *[C.byref(x) for x in v], C.byref(steps)))
+        return {"available": bool(v[0].value), "cols": (v[1].value, v[2].value), "rows": (v[3].value, v[4].value),
+                "steps": steps.value}
 
     def placement_info(self):
         n, ms, sp = C.c_int(), C.c_double(), C.c_int()

@@ -1,0 +1,89 @@
+"""Two iterations per launch (ds_iterate on whole-image f32 handles with D = 64 / 128 / 256)
+against one iteration per launch (DS_FUSED2=off) and the O(D) oracle.  Needs a GPU.
+
+Bar: bit-identical phi (integer-exact comparison of the float bit patterns via array_equal),
+identical labels, equal energy."""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle.pyoracle import FastOracle
+from tests.util import random_pair, random_phi
+
+pytestmark = pytest.mark.gpu
+
+load_package()
+from stereo_vision_amd import diffstereo, synth  # noqa: E402
+
+# (H, W, D): interiors of a few strips and a few rows; odd widths; rows whose count is odd
+SHAPES = [(20, 400, 256), (21, 333, 256), (30, 700, 128), (17, 421, 128), (24, 600, 64), (17, 390, 64),
+          (45, 330, 256)]
+
+
+@pytest.mark.parametrize("H,W,D", SHAPES)
+def test_pairs_of_iterations_equal_single_iterations(monkeypatch, H, W, D):
+    left, right = random_pair(H, W, seed=H + W + D)
+    phi0 = random_phi(H, W, D, "f32", seed=7)
+    g2 = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    info = g2.fused2_info()
+    assert info["available"] and info["cols"][0] < info["cols"][1] and info["rows"] == (4, H - 4)
+    monkeypatch.setenv("DS_FUSED2", "off")
+    g1 = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    monkeypatch.delenv("DS_FUSED2")
+    assert not g1.fused2_info()["available"]
+    f = FastOracle(left, right, D, 1.2, dtype="f32")
+    for g in (g1, g2):
+        g.set_phi(phi0)
+    f.potentials[...] = phi0
+    steps = 0
+    for n in (3, 4, 7, 2, 1, 5):   # 1, 1, 3, 0, 0, 2 two-iteration steps
+        g1.iterate(n)
+        g2.iterate(n)
+        f.iterate(n)
+        steps += (n - 1) // 2
+        phi = g2.get_phi()
+        assert np.array_equal(phi, g1.get_phi()), "after a call of %d iterations" % n
+        assert np.array_equal(phi, f.potentials), "oracle, after a call of %d iterations" % n
+    assert g2.fused2_info()["steps"] == steps and g1.fused2_info()["steps"] == 0
+    assert g2.checksum() == g1.checksum()
+    assert g2.energy() == g1.energy()
+    assert np.array_equal(g2.labels(0), f.labels(0))
+    g1.close()
+    g2.close()
+
+
+def test_handles_without_an_interior_fall_back():
+    for H, W, D, dtype in ((20, 290, 256, "f32"), (11, 400, 256, "f32"), (20, 400, 200, "f32"), (20, 400, 256, "f64")):
+        left, right = random_pair(H, W, seed=3)
+        g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+        assert not g.fused2_info()["available"], (H, W, D, dtype)
+        g.iterate(5)
+        f = FastOracle(left, right, D, 1.2, dtype=dtype)
+        f.iterate(5)
+        assert np.array_equal(g.get_phi(), f.potentials)
+        g.close()
+    band = diffstereo.DiffusionGraph(*random_pair(40, 400, seed=1), 256, 1.2, dtype="f32", row_begin=0, row_end=20)
+    assert not band.fused2_info()["available"]
+    band.close()
+
+
+def test_full_size_4k_256(monkeypatch):
+    """The benchmark's own size: checksum, energy and labels equal to one iteration per launch
+    after 9 iterations (4 two-iteration steps + 1), top rows bit-exact against the oracle."""
+    H, W, D = 2160, 3840, 256
+    monkeypatch.setenv("DS_PLACEMENT_TRIES", "2")
+    left, right, _ = synth.synthetic_pair(H, W, D)
+    g2 = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    g2.iterate(9)
+    assert g2.fused2_info()["steps"] == 4
+    c2, e2, l2 = g2.checksum(), g2.energy(), g2.labels(0)
+    top = g2.get_phi(0, 20)
+    g2.close()
+    monkeypatch.setenv("DS_FUSED2", "off")
+    g1 = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    g1.iterate(9)
+    assert g1.checksum() == c2 and g1.energy() == e2 and np.array_equal(g1.labels(0), l2)
+    g1.close()
+    f = FastOracle(left[:40], right[:40], D, 1.2, dtype="f32")
+    f.iterate(9)
+    assert np.array_equal(top, f.potentials[:20])
