@@ -9,7 +9,10 @@
 //   D  black(i) of iteration n+2, stored
 // Step i runs A(i+1), B(i), C(i-1), D(i-2).  Per (pixel, label) and per TWO iterations the kernel
 // reads 4 rows of the second colour and writes 4, i.e. half the one-iteration kernel's traffic;
-// it is bound by the vector ALU instead.  NP slots yield NP - 3 finished column pairs (A needs all
+// it is bound by the vector ALU instead.  Blocks of 12 wavefronts: the kernel wants about 160
+// vector registers, which three wavefronts per SIMD leave it; with 16-wavefront blocks (128
+// registers) it spills, and every reload also waits for the row loads in flight (measured at
+// 4K x 256: 11.3 ms per launch against 9.8).  NP slots yield NP - 3 finished column pairs (A needs all
 // NP, B NP - 1, C NP - 2, D NP - 3): a strip of FC2 = 2 (NP - 3) output columns whose first is
 // c0 + 2, c0 = col_begin - 2 + blockIdx.x * FC2, reads columns c0 - 2 .. c0 + 2 NP.
 //
@@ -121,83 +124,13 @@ __device__ __forceinline__ void messages_lean(const V4<float> psi[4], const floa
     }
 }
 
-// The same once more with the additions two labels at a time (v_pk_add_f32 / v_pk_mul_f32: the
-// same IEEE operations on register pairs).  Returns out[n] = avg - M[n] directly.
-typedef float F2 __attribute__((ext_vector_type(2)));
-
-template <int LPP>
-__device__ __forceinline__ void update_packed(const V4<float> psi[4], uint32_t cost_word, const F2 lam2[2], float lam1,
-                                              int lseg, int rev4, V4<float> out[4])
-{
-    using R = Real<float>;
-    const float inf = R::inf();
-    const int pslot[3] = {1, 2, 3}, sslot[3] = {0, 1, 3};
-    F2 a[3][2], b[3][2];
-    float x[6];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const V4<float> &u = psi[pslot[t]], &w = psi[sslot[t]];
-        a[t][0] = F2{u.v[0], u.v[1]} - lam2[0];
-        a[t][1] = F2{u.v[2], u.v[3]} - lam2[1];
-        b[t][0] = F2{w.v[0], w.v[1]} + lam2[0];
-        b[t][1] = F2{w.v[2], w.v[3]} + lam2[1];
-        const float pa = R::min(R::min(R::min(a[t][0].x, a[t][0].y), a[t][1].x), a[t][1].y);
-        const float pb = R::min(R::min(R::min(b[t][1].y, b[t][1].x), b[t][0].y), b[t][0].x);
-        float up = dpp<DPP_WAVE_SHR1>(inf, pa);
-        if (LPP < 64) up = (lseg == 0) ? inf : up;
-        x[t] = up;
-        const float mirrored = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rev4 + 4, __builtin_bit_cast(int, pb)));
-        x[3 + t] = (lseg == 0) ? inf : mirrored;
-    }
-    prefix_scans6<LPP>(x);
-    F2 fwd[3][2], bwd[3][2];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const float down = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rev4, __builtin_bit_cast(int, x[3 + t])));
-        const float f0 = R::min(x[t], a[t][0].x), f1 = R::min(f0, a[t][0].y), f2 = R::min(f1, a[t][1].x),
-                    f3 = R::min(f2, a[t][1].y);
-        const float e3 = R::min(down, b[t][1].y), e2 = R::min(e3, b[t][1].x), e1 = R::min(e2, b[t][0].y),
-                    e0 = R::min(e1, b[t][0].x);
-        fwd[t][0] = F2{f0, f1} + lam2[0];
-        fwd[t][1] = F2{f2, f3} + lam2[1];
-        bwd[t][0] = F2{e0, e1} - lam2[0];
-        bwd[t][1] = F2{e2, e3} - lam2[1];
-    }
-    float prev = dpp<DPP_WAVE_SHR1>(inf, psi[0].v[3]);
-    float next = dpp<DPP_WAVE_SHL1>(inf, psi[2].v[0]);
-    if (LPP < 64) {
-        prev = (lseg == 0) ? inf : prev;
-        next = (lseg == LPP - 1) ? inf : next;
-    }
-    const F2 l1 = {lam1, lam1};
-    const F2 left[2] = {l1 + F2{prev, psi[0].v[0]}, l1 + F2{psi[0].v[1], psi[0].v[2]}};
-    const F2 right[2] = {l1 + F2{psi[2].v[1], psi[2].v[2]}, l1 + F2{psi[2].v[3], next}};
-    const F2 quarter = {0.25f, 0.25f};
-#pragma unroll
-    for (int hlf = 0; hlf < 2; ++hlf) {
-        F2 M[4];
-        M[0] = F2{R::min(bwd[0][hlf].x, left[hlf].x), R::min(bwd[0][hlf].y, left[hlf].y)};
-        M[1] = F2{R::min(fwd[0][hlf].x, bwd[1][hlf].x), R::min(fwd[0][hlf].y, bwd[1][hlf].y)};
-        M[2] = F2{R::min(fwd[1][hlf].x, right[hlf].x), R::min(fwd[1][hlf].y, right[hlf].y)};
-        M[3] = F2{R::min(fwd[2][hlf].x, bwd[2][hlf].x), R::min(fwd[2][hlf].y, bwd[2][hlf].y)};
-        const F2 q = {(float)((cost_word >> (16 * hlf)) & 0xffu), (float)((cost_word >> (16 * hlf + 8)) & 0xffu)};
-        const F2 avg = (q + (((M[0] + M[1]) + M[2]) + M[3])) * quarter;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const F2 o = avg - M[n];
-            out[n].v[2 * hlf] = o.x;
-            out[n].v[2 * hlf + 1] = o.y;
-        }
-    }
-}
-
 template <typename T, int NP, int DL> struct Fused2Lds {
     T ring1[2][NP][DL];  // A: red -> the neighbouring slot's black (iteration n+1)
     T ring2[2][NP][DL];  // B: black -> the neighbouring slot's red (iteration n+2)
     T ring3[2][NP][DL];  // C: red -> the neighbouring slot's black (iteration n+2)
 };
 
-template <typename T, int LPP, int FW, int VARIANT = 3>
+template <typename T, int LPP, int FW>
 __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, const T *__restrict__ phi,
                                                                    T *__restrict__ phi_out, FusedPlanes np,
                                                                    const uint8_t *__restrict__ cost, T lambda,
@@ -223,19 +156,10 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     const int kl = kp > 0 ? kp - 1 : 0, kr = kp < NP - 1 ? kp + 1 : NP - 1;  // neighbouring slots (clamped: the
                                                                               // strip's outermost slots are not kept)
     using V = V4<T>;
-    F2 lam2[2];
-    if constexpr (sizeof(T) == 4) {
-        lam2[0] = F2{(float)lam[0], (float)lam[1]};
-        lam2[1] = F2{(float)lam[2], (float)lam[3]};
-    }
     auto update = [&](const V psi[4], uint32_t cost_word, V out[4]) {
-        if constexpr (sizeof(T) == 4 && (VARIANT & 4)) {
-            update_packed<LPP>(psi, cost_word, lam2, lambda, lseg, rev4, out);
-            return;
-        }
         V M[4];
         const V qc = unpack_cost<T>(cost_word);
-        if constexpr (sizeof(T) == 4 && (VARIANT & 1)) messages_lean<LPP>(psi, lam, lambda, lseg, rev4, M);
+        if constexpr (sizeof(T) == 4) messages_lean<LPP>(psi, lam, lambda, lseg, rev4, M);
         else messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -342,12 +266,11 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         using Same = std::integral_constant<int, P>;
         using Other = std::integral_constant<int, 1 - P>;
         stage_a(Other{});
-        if constexpr (!(VARIANT & 2)) { if (i + 2 < r1 + 3) fetch(i + 2, Same{}); }
         stage_b(i, Same{});
         if (i - 1 >= r0 - 1) stage_c(i - 1, Other{});
         // the next step's loads: in flight through stage D and the barrier (they are not needed
         // earlier, and their sixteen registers are free for stages B and C this way)
-        if constexpr (VARIANT & 2) { if (i + 2 < r1 + 3) fetch(i + 2, Same{}); }
+        if (i + 2 < r1 + 3) fetch(i + 2, Same{});
         if (i - 2 >= r0) stage_d(i - 2, Same{});
         rotate();
         __syncthreads();

@@ -173,21 +173,28 @@ def test_error_paths():
 
 
 def test_placement_does_not_change_results(monkeypatch):
-    """A problem large enough for ds_create to place phi in two separately allocated plane
-    groups (and to probe placements) must give the same bits as one plain allocation."""
+    """DS_PLACEMENT=search (phi in two separately allocated plane groups, placements timed at
+    ds_create) must give the same bits as the default, one plain allocation."""
     H, W, D = 258, 2048, 256
     left, right, _ = synth.synthetic_pair(H, W, D)
-    monkeypatch.setenv("DS_PLACEMENT_TRIES", "3")
     a = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
     info = a.placement_info()
-    assert info["split"] and 1 <= info["tries"] <= 3 and info["probe_ms"] > 0
-    monkeypatch.setenv("DS_PLACEMENT", "off")
+    assert info == {"tries": 0, "probe_ms": 0.0, "split": False}  # the default: one plain allocation
+    monkeypatch.setenv("DS_PLACEMENT", "search")
+    monkeypatch.setenv("DS_PLACEMENT_TRIES", "2")
+    c = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    info = c.placement_info()
+    assert info["split"] and 1 <= info["tries"] <= 2 and info["probe_ms"] > 0
+    assert c.checksum() == 0  # probing leaves phi in its initial state
+    c.iterate(3)
+    monkeypatch.setenv("DS_PLACEMENT", "off")  # any other value: the default
     b = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
     assert b.placement_info() == {"tries": 0, "probe_ms": 0.0, "split": False}
-    assert a.checksum() == b.checksum() == 0  # probing leaves phi in its initial state
+    assert a.checksum() == b.checksum() == 0
     a.iterate(3)
     b.iterate(3)
-    assert a.checksum() == b.checksum()
+    assert a.checksum() == b.checksum() == c.checksum()
+    c.close()
     assert np.array_equal(a.labels(0), b.labels(0))
     ea, eb = a.energy(), b.energy()
     assert ea == eb
