@@ -19,7 +19,7 @@ HEADER = os.path.join(ROOT, "include", "diffstereo.h")
 def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ds_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
@@ -29,7 +29,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol():
     lib = diffstereo.lib()  # raises if the .so is missing or a symbol is not exported
     out = subprocess.check_output(["nm", "-D", "--defined-only", diffstereo.LIB_PATH], text=True)
-    exported = set(re.findall(r"\bT (ds_[a-z_]+)\b", out))
+    exported = set(re.findall(r"\bT (ds_[a-z0-9_]+)\b", out))
     assert exported == set(declared_symbols())
     assert lib.ds_create is not None
 
@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 def test_static_library_holds_the_same_objects():
     a = os.path.join(os.path.dirname(diffstereo.LIB_PATH), "libdiffstereo.a")
     out = subprocess.check_output(["nm", "--defined-only", a], text=True)
-    assert set(re.findall(r"\bT (ds_[a-z_]+)\b", out)) == set(declared_symbols())
+    assert set(re.findall(r"\bT (ds_[a-z0-9_]+)\b", out)) == set(declared_symbols())
 
 
 def test_argument_validation_needs_no_gpu():
