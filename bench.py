@@ -56,10 +56,13 @@ def pmc_traffic(workload, kernel):
     (profiles/pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs,
     FETCH_SIZE doubled as gfx950 requires); None if no pass matches this kernel."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))[workload]
-        return float(rec["hbm_bytes_per_launch"]) if rec["kernel"] == kernel else None
-    except (OSError, KeyError, ValueError):
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+    except (OSError, ValueError):
         return None
+    for key, rec in table.items():
+        if key.startswith(workload) and rec.get("kernel") == kernel:
+            return float(rec["hbm_bytes_per_launch"])
+    return None
 
 
 def cpu_baseline(left, right, D, lam, budget_s=12.0):
