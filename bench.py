@@ -105,6 +105,56 @@ def cpu_baseline(left, right, D, lam, budget_s=12.0):
     return out
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block (for libraries that print from C)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.keep = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.keep, 1)
+        os.close(self.keep)
+        return False
+
+
+class SingleGpu:
+    """One GPU: the whole image through ds_iterate, or (--band-of) one band's kernels in the
+    order the band protocol launches them, without a neighbour to exchange with."""
+
+    def __init__(self, graph):
+        self.g = graph
+        self.whole = graph.row_begin == 0 and graph.row_end == graph.H
+
+    def iterate(self, n):
+        g = self.g
+        if self.whole:
+            g.iterate(n)
+            return
+        fb, fe = g.fused_rows()
+        if n <= 0 or fe - fb < 4:
+            for _ in range(n):
+                g.sweep(0)
+                g.sweep(1)
+            g.synchronize()
+            return
+        for _ in range(n):
+            if fb > g.row_begin:
+                g.sweep(0, g.row_begin, g.row_begin + 2)
+                g.sweep_next(g.row_begin, g.row_begin + 1)
+            if fe < g.row_end:
+                g.sweep(0, g.row_end - 2, g.row_end)
+                g.sweep_next(g.row_end - 1, g.row_end)
+            g.iterate_rows(fb, fe)
+        g.finish_iterations()
+        g.synchronize()
+
+    def energy(self):
+        return self.g.energy()
+
+
 def spawn_ranks(n):
     """Run this script as n child processes (ranks 0..n-1, one per GPU) with the environment
     torch.distributed.run would give them; returns the first non-zero exit status, else 0."""
@@ -174,17 +224,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # gloo is the control plane only (the communicator's id, barriers, the max over ranks);
         # the halo rows travel over RCCL inside the library
-        # (gloo reports its connections on stdout: keep that away from the one JSON line)
-        sys.stdout.flush()
-        keep = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        # (gloo and RCCL report on stdout when they connect: keep that away from the one JSON line)
+        with stdout_to_stderr():
             dist.init_process_group("gloo")
             dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(keep, 1)
-            os.close(keep)
 
     def all_agree(ok):
         t = torch.tensor([1 if ok else 0], dtype=torch.int32)
@@ -204,7 +247,7 @@ def main():
     transport, comm = "none", None
     if world == 1:
         # the whole image through ds_iterate; --band-of: the band's kernels without a neighbour
-        runner = bands.BandRunner(bands.HipBandEngine(graph), rank=0, world=1)
+        runner = SingleGpu(graph)
     else:
         if not rehearsal:
             # Preflight, in steps every rank can fail at without leaving its peers inside a
@@ -215,9 +258,10 @@ def main():
             ok = diffstereo.lib().ds_comm_unique_id(probe) == 0
             if all_agree(ok):
                 try:
-                    comm = bands.RcclComm(rank, world, local_rank)
-                    runner = bands.Bands(graph, comm, rank, world)
-                    runner.exchange_all()
+                    with stdout_to_stderr():
+                        comm = bands.RcclComm(rank, world, local_rank)
+                        runner = bands.Bands(graph, comm, rank, world)
+                        runner.exchange_all()
                 except Exception as exc:  # noqa: BLE001
                     ok = False
                     print("rank %d: RCCL halo exchange failed: %r" % (rank, exc), file=sys.stderr, flush=True)

@@ -19,9 +19,9 @@ siblings in include/diffstereo.h) over the library's own RCCL transport (`RcclCo
 transport supplied from here (`GlooTransport`: through host memory, for ranks that share one
 GPU and for machines where RCCL point-to-point is unavailable).
 
-`BandRunner` states the same protocol in engine-agnostic form: the engine supplies the sweep
-and the halo buffers (`HipBandEngine` over the C ABI's building blocks, or a CPU engine in the
-tests, which is how the protocol itself is checked without a GPU).
+`BandRunner` states the same protocol in engine-agnostic Python: the engine supplies the sweep
+and the halo buffers.  It is how the protocol itself is checked without a GPU (the tests run
+it over a CPU engine with 2-4 gloo ranks); the product does not use it.
 """
 import contextlib
 import ctypes as C
@@ -187,149 +187,6 @@ class Bands:
 
     def crossing_out(self, epsilon, max_passes=1 << 30, with_mask=False):
         return self._guard(self.g.band_crossing_out, epsilon, max_passes, with_mask)
-
-
-class _DeviceBytes:
-    """Zero-copy view of library-owned device memory for torch.as_tensor."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
-                                         "data": (ptr, False), "version": 2}
-
-
-class HipBandEngine:
-    """One band on the current GPU, driven through the C ABI."""
-
-    def __init__(self, graph, stage_through_host=False):
-        self.g = graph
-        self.row_begin, self.row_end = graph.row_begin, graph.row_end
-        self.H = graph.H
-        self.stage = stage_through_host  # gloo rehearsal: halos travel via pinned host copies
-        self._views = {}
-        # A main stream of the engine's own rather than whatever stream is current when the
-        # engine is made: the two streams below are then ordered by this class's events alone
-        # (the legacy default stream would add its implicit synchronisation with blocking streams).
-        self.main = torch.cuda.Stream()
-        self.main.wait_stream(torch.cuda.current_stream())
-        # boundary rows + exchanges beside the interior kernel.  Normal priority on purpose: with a
-        # high-priority stream in the chain main -> side -> RCCL's stream -> side -> main the
-        # device never drained (seen with RCCL send/recv on one MI355X), and the chain is queued
-        # before the interior kernel anyway, so its first launch does not wait behind it.
-        self.side = torch.cuda.Stream()
-        graph.set_stream(self.main.cuda_stream)
-
-    def beside(self):
-        """Context: library launches and torch work go to the side stream, which first waits for
-        everything queued on the main stream so far.  join() makes the main stream wait for it."""
-        engine = self
-
-        class _Beside:
-            def __enter__(self):
-                engine.side.wait_stream(engine.main)
-                self._ctx = torch.cuda.stream(engine.side)
-                self._ctx.__enter__()
-                engine.g.switch_stream(engine.side.cuda_stream)
-
-            def __exit__(self, *exc):
-                engine.g.switch_stream(engine.main.cuda_stream)
-                return self._ctx.__exit__(*exc)
-
-        return _Beside()
-
-    def join(self):
-        self.main.wait_stream(self.side)
-
-    def on_main(self):
-        """Context for everything BandRunner queues: torch's current stream = the engine's main
-        stream, so that the communication library orders itself against the library's launches."""
-        return torch.cuda.stream(self.main)
-
-    def _view(self, colour, side, which, upcoming=False):
-        # the library alternates between two sets of colour-1 planes: views are kept per pointer
-        ptr, nbytes = self.g.halo_next(side, which) if upcoming else self.g.halo(colour, side, which)
-        if ptr not in self._views:
-            self._views[ptr] = torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
-        return self._views[ptr]
-
-    def sweep(self, colour, row_begin, row_end):
-        if row_end > row_begin:
-            self.g.sweep(colour, row_begin, row_end)
-
-    def iterate(self, n_iters):
-        self.g.iterate(n_iters)
-
-    # whole iterations in one kernel on a band (include/diffstereo.h, ds_iterate_rows)
-    def fused_rows(self):
-        return self.g.fused_rows()
-
-    def iterate_rows(self, row_begin, row_end):
-        self.g.iterate_rows(row_begin, row_end)
-
-    def sweep_next(self, row_begin, row_end):
-        if row_end > row_begin:
-            self.g.sweep_next(row_begin, row_end)
-
-    def sweep_pair(self, colour, upcoming, rows1, rows2):
-        self.g.sweep_pair(colour, upcoming, rows1, rows2)
-
-    def finish_iterations(self):
-        self.g.finish_iterations()
-
-    def send_buffer_next(self, side):
-        v = self._view(1, side, 0, upcoming=True)
-        return v.cpu() if self.stage else v
-
-    def recv_buffer_next(self, side):
-        v = self._view(1, side, 1, upcoming=True)
-        return (torch.empty(v.shape, dtype=v.dtype), v) if self.stage else (v, v)
-
-    def send_buffer(self, colour, side):
-        v = self._view(colour, side, 0)
-        return v.cpu() if self.stage else v
-
-    def recv_buffer(self, colour, side):
-        v = self._view(colour, side, 1)
-        return torch.empty(v.shape, dtype=v.dtype) if self.stage else v
-
-    def commit_recv(self, colour, side, buf):
-        if self.stage:
-            self._view(colour, side, 1).copy_(buf)
-
-    def energy(self):
-        return self.g.energy()
-
-    # crossing-out: the mask halo rows travel like the phi halo rows
-    def co_begin(self, epsilon):
-        self.g.co_begin(epsilon)
-        self._co_views = {}
-
-    def co_pass(self):
-        return self.g.co_pass()
-
-    def _co_view(self, colour, side, which):
-        key = (colour, side, which)
-        if key not in self._co_views:
-            ptr, nbytes = self.g.co_halo(colour, side, which)
-            self._co_views[key] = torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
-        return self._co_views[key]
-
-    def co_send_buffer(self, colour, side):
-        v = self._co_view(colour, side, 0)
-        return v.cpu() if self.stage else v
-
-    def co_recv_buffer(self, colour, side):
-        v = self._co_view(colour, side, 1)
-        return torch.empty(v.shape, dtype=v.dtype) if self.stage else v
-
-    def co_commit_recv(self, colour, side, buf):
-        if self.stage:
-            self._co_view(colour, side, 1).copy_(buf)
-
-    def co_finish(self, empty, with_mask=False):
-        return self.g.co_finish(empty, with_mask)
-
-    def synchronize(self):
-        self.main.synchronize()
 
 
 class BandRunner:

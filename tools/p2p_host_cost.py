@@ -1,13 +1,11 @@
-"""Host-side cost of the halo exchange calls: torch.distributed batch_isend_irecv on the
-nccl (RCCL) backend with this rank as its own peer (world size 1), next to the cost of
-the sweep launches of one band.  A one-GPU estimate of the per-iteration host time of a
-multi-GPU rank; the transfers themselves are not representative."""
+"""One of eight row bands of the 4K x 256 workload iterated by the library's band protocol
+(ds_band_iterate) over its own RCCL transport, with this rank as both of its neighbours
+(world size 1, ncclSend / ncclRecv to self).  A one-GPU estimate of what a rank of an 8-GPU job
+spends per iteration; the transfers themselves are not representative of xGMI.
+env: BANDS (default 8), BAND (default 3), WORKLOAD dims H W D, DTYPE."""
 import os
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package  # noqa: E402
@@ -15,37 +13,25 @@ from __graft_entry__ import load_package  # noqa: E402
 load_package()
 from stereo_vision_amd import bands, diffstereo, synth  # noqa: E402
 
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29533")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-H, W, D = 2160, 3840, 256
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+H, W, D = (int(os.environ.get(k, v)) for k, v in (("H", 2160), ("W", 3840), ("D", 256)))
+n_bands, which = int(os.environ.get("BANDS", 8)), int(os.environ.get("BAND", 3))
+dtype = os.environ.get("DTYPE", "f32")
 left, right, _ = synth.synthetic_pair(H, W, D)
-rb, re = bands.partition_rows(H, 8)[3]
-g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32", row_begin=rb, row_end=re)
-# DUMMY_STREAMS=n: n more streams that have run work, created before the engine's two, to see
-# whether the engine's streams still overlap when streams outnumber the hardware queues
-dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("DUMMY_STREAMS", "0")))]
-for st in dummies:
-    with torch.cuda.stream(st):
-        torch.zeros(8, device="cuda").add_(1)
-torch.cuda.synchronize()
-eng = bands.HipBandEngine(g)
-runner = bands.BandRunner(eng, rank=0, world=1)
-runner.up = runner.down = 0      # loop the exchange back to this rank
-runner.world = 2                 # take the multi-rank branch of half_sweep
-try:
-    runner.iterate(2)
-    torch.cuda.synchronize()
-    n = 50
-    t0 = time.perf_counter()
-    runner.iterate(n)
-    t_host = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    t_all = time.perf_counter() - t0
-    print("band of %d rows: host returns after %.3f ms per iteration, GPU done after %.3f ms per iteration"
-          % (re - rb, t_host / n * 1e3, t_all / n * 1e3), flush=True)
-except Exception as exc:  # noqa: BLE001
-    print("loopback exchange not possible here: %r" % (exc,), flush=True)
+rb, re = bands.partition_rows(H, n_bands)[which]
+g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype, row_begin=rb, row_end=re, device=0)
+comm = bands.RcclComm(0, 1, 0)
+runner = bands.Bands(g, comm, 0, 1, up=0 if rb > 0 else -1, down=0 if re < H else -1)
+runner.iterate(3)
+n = int(os.environ.get("N", 50))
+g.profile_begin(8 * n + 8)
+t0 = time.perf_counter()
+runner.iterate(n)
+wall = time.perf_counter() - t0
+g.profile_end()
+print("band %d of %d (rows %d-%d), %s: %.3f ms per iteration over RCCL loopback" % (which, n_bands, rb, re, dtype, wall / n * 1e3))
+for kind, name in ((0, "boundary half-sweeps"), (1, "interior kernel")):
+    k, ms = g.profile_kind(kind)
+    print("  %-22s %4d launches, %.3f ms per iteration" % (name, k, ms / n))
 g.close()
-dist.destroy_process_group()
+comm.close()
