@@ -159,20 +159,21 @@ int need_attached(ds_handle *h, const char *who)
     return DS_OK;
 }
 
-// Halo row of phi: device pointer and size (see ds_halo).  upcoming = the colour-1 planes the
-// running iteration is producing instead of the current ones.
-void halo_row(const ds_handle *h, int colour, bool upcoming, int side, int which, void **ptr, size_t *bytes)
+// Halo row of phi: device pointer and size (see ds_halo).  planes: the four plane offsets of
+// the set the row belongs to (a colour's current planes, or the set an iteration is producing).
+void halo_row(const ds_handle *h, const long long *planes, int side, int which, void **ptr, size_t *bytes)
 {
     const ds::Geometry &g = h->g;
     const int slot = side == 0 ? (which == 0 ? 1 : 3) : (which == 0 ? 3 : 1);
     const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
-    const long long plane = upcoming ? h->alt_off[slot] : g.plane_off[colour][slot];
-    *ptr = static_cast<char *>(h->phi) + (size_t)(plane + (long long)il * g.row_stride) * h->elem;
+    *ptr = static_cast<char *>(h->phi) + (size_t)(planes[slot] + (long long)il * g.row_stride) * h->elem;
     *bytes = (size_t)g.Wh * g.Dpad * h->elem;
 }
 
-// The exchange that follows a colour's half-sweep, queued on `stream`.
-int exchange_phi(ds_handle *h, int colour, bool upcoming, hipStream_t stream)
+// The exchange that follows a colour's half-sweep, queued on `stream`: the band's first row's
+// upward messages to the rank above, its last row's downward messages to the rank below, and
+// the mirror images into the halo rows.
+int exchange_planes(ds_handle *h, const long long *planes, hipStream_t stream)
 {
     int peers[2], n = 0;
     void *send[2], *recv[2];
@@ -181,14 +182,20 @@ int exchange_phi(ds_handle *h, int colour, bool upcoming, hipStream_t stream)
         const int peer = side == 0 ? h->up : h->down;
         if (peer < 0) continue;
         peers[n] = peer;
-        halo_row(h, colour, upcoming, side, 0, &send[n], &bytes[n]);
-        halo_row(h, colour, upcoming, side, 1, &recv[n], &bytes[n]);
+        halo_row(h, planes, side, 0, &send[n], &bytes[n]);
+        halo_row(h, planes, side, 1, &recv[n], &bytes[n]);
         ++n;
     }
     if (n == 0) return DS_OK;
     if (h->transport.exchange(h->transport.ctx, n, peers, send, recv, bytes, stream) != 0)
         return transport_fail(h, "the halo exchange");
     return DS_OK;
+}
+
+// upcoming = the colour-1 planes the running iteration is producing instead of the current ones
+int exchange_phi(ds_handle *h, int colour, bool upcoming, hipStream_t stream)
+{
+    return exchange_planes(h, upcoming ? h->alt_off : h->g.plane_off[colour], stream);
 }
 
 // One colour of a band that sweeps colour by colour: boundary rows, their exchange beside the
@@ -229,6 +236,64 @@ int band_fused_iteration(ds_handle *h, int fb, int fe)
     if (rc == DS_OK) rc = launch_fused(h, fb, fe);  // handle's stream; makes the produced planes current
     if (rc == DS_OK) rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
     return rc;
+}
+
+// Two iterations of a band in one step (see fused2_step in diffstereo.hip for the whole image):
+// the two-iteration kernel over the band's interior on the handle's stream; on the boundary
+// stream, the frame around it through the one-iteration kernel twice (X -> Y -> Z), and for the
+// band's first / last row, which that kernel cannot take next to a neighbour, the half-sweeps
+// of the one-iteration protocol, twice, each followed by its exchange: first colour from X,
+// exchange, second colour into Y, exchange, first colour from Y, exchange, second colour into
+// Z, exchange -- the same messages in the same order as two single iterations, so a band that
+// steps by two may have neighbours that do not.
+int band_fused2_step(ds_handle *h)
+{
+    ds::Geometry &g = h->g;
+    const ds_handle::Fused2Plan &p = h->plan2;
+    const int rb = g.row0, re = g.row0 + g.Hb;
+    const bool up = h->up >= 0, down = h->down >= 0;
+    const long long *X = g.plane_off[1], *Y = h->y_off, *Z = h->alt_off;
+    const int all = (g.W + p.strip1 - 1) / p.strip1;
+    const int right0 = p.cR - p.strip1, right_strips = (g.W - right0 + p.strip1 - 1) / p.strip1;
+    // rows the one-iteration kernel takes at the top / bottom of the band (a band's own first /
+    // last row only where the image ends there)
+    const int top0 = up ? rb + 1 : rb, bot1 = down ? re - 1 : re;
+    auto sweep_boundary = [&](int colour, const long long *black) -> int {
+        ds::Geometry geo = g;
+        for (int s = 0; s < 4; ++s) geo.plane_off[1][s] = black[s];
+        const int n = colour == 0 ? 2 : 1;  // the first colour's two rows feed the second colour's one
+        return launch_sweep(h, colour, rb, up ? rb + n : rb, &geo, down ? re - n : re, re);
+    };
+    int rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
+    if (rc != DS_OK) return rc;
+    rc = on_side_stream(h, [&]() -> int {
+        hipStream_t side = h->side_stream;
+        // iteration n + 1 on the widened frame: X -> Y
+        int r = launch_fused_region(h, X, Y, 0, all, top0, p.rT + 2, 1);
+        if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, all, p.rB - 2, bot1, 1);
+        if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2, 1);
+        if (r == DS_OK) r = launch_fused_region(h, X, Y, right0, right_strips, p.rT + 2, p.rB - 2, 1);
+        if (r == DS_OK) r = sweep_boundary(0, X);
+        if (r == DS_OK) r = exchange_planes(h, g.plane_off[0], side);
+        if (r == DS_OK) r = sweep_boundary(1, Y);
+        if (r == DS_OK) r = exchange_planes(h, Y, side);
+        // iteration n + 2 on the frame: Y -> Z
+        if (r == DS_OK) r = sweep_boundary(0, Y);
+        if (r == DS_OK) r = exchange_planes(h, g.plane_off[0], side);
+        if (r == DS_OK) r = sweep_boundary(1, Z);
+        if (r == DS_OK) r = exchange_planes(h, Z, side);
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, top0, p.rT, 1);
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, p.rB, bot1, 1);
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, p.cL / p.strip1, p.rT, p.rB, 1);
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB, 1);
+        return r;
+    });
+    if (rc == DS_OK) rc = launch_fused2_interior(h);
+    if (rc == DS_OK) rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
+    if (rc != DS_OK) return rc;
+    for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
+    h->fused_pending = true;
+    return DS_OK;
 }
 
 int reduce_scalar(ds_handle *h, void *dev, int count, int kind)
@@ -402,7 +467,15 @@ int ds_band_iterate(ds_handle *h, int n_iters)
     if (h->fused_waves) fused_safe_rows(h, &fb, &fe);
     const bool fused = n_iters > 0 && fe - fb >= 4 && g.Hb >= 8;
     if (fused) {
-        for (int it = 0; it < n_iters && rc == DS_OK; ++it) rc = band_fused_iteration(h, fb, fe);
+        // two iterations per step while more than two remain (the last one runs alone: see ds_iterate)
+        int left = n_iters;
+        if (left >= 3 && prepare_fused2(h)) {
+            for (; left >= 3 && rc == DS_OK; left -= 2) {
+                rc = band_fused2_step(h);
+                ++h->fused2_steps;
+            }
+        }
+        for (int it = 0; it < left && rc == DS_OK; ++it) rc = band_fused_iteration(h, fb, fe);
         if (rc == DS_OK) rc = materialise_first_colour(h, g.row0, g.row0 + g.Hb);
     } else {
         for (int it = 0; it < n_iters && rc == DS_OK; ++it)

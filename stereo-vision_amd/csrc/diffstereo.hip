@@ -412,7 +412,9 @@ int need_side_stream(ds_handle *h)
 // to two pixels away), then Y -> Z on the frame itself.  Z is also where the two-iteration
 // kernel writes, so after the step Z holds iteration n + 2 everywhere and becomes current.
 // The frame's eight launches run on the side stream beside the interior kernel: both read X
-// only (and Y, which nothing else touches) and write disjoint parts of Z.
+// only (and Y, which nothing else touches) and write disjoint parts of Z.  On a row band the
+// rows next to a neighbouring band also need that band's rows after each of the two iterations:
+// band_fused2_step (bands.hpp) runs the band protocol on them, twice.
 void plan_fused2(ds_handle *h)
 {
     ds_handle::Fused2Plan &p = h->plan2;
@@ -420,7 +422,7 @@ void plan_fused2(ds_handle *h)
     const ds::Geometry &g = h->g;
     const char *e = std::getenv("DS_FUSED2");
     if (e && std::strcmp(e, "off") == 0) return;
-    if (h->dtype != DS_F32 || h->fused_waves != 16 || g.row0 != 0 || g.Hb != g.H || g.D != 4 * h->lpp) return;
+    if (h->dtype != DS_F32 || h->fused_waves != 16 || g.D != 4 * h->lpp) return;
     p.waves = 16;
     p.waves = 12;
     if (const char *w = std::getenv("DS_F2_WAVES")) p.waves = std::atoi(w) == 16 ? 16 : 12;  // tuning knob
@@ -430,11 +432,16 @@ void plan_fused2(ds_handle *h)
     const long long room = (long long)g.W - 1 - 2 * NP - (p.cL - 2);  // c0 of the last strip + 2 NP < W
     p.strips = room >= 0 ? (int)(room / FC2) + 1 : 0;
     p.cR = p.cL + p.strips * FC2;
-    p.rT = 4;
-    p.rB = g.H - 4;
+    // Rows: every pixel any stage touches needs four neighbours, and the first stage reads the
+    // second colour four rows beyond the output rows.  At the image's top / bottom that leaves out
+    // four rows; next to a neighbouring band three (the band holds one halo row beyond its own).
+    p.rT = g.row0 == 0 ? 4 : g.row0 + 3;
+    p.rB = g.row0 + g.Hb == g.H ? g.H - 4 : g.row0 + g.Hb - 3;
     p.strip1 = FC1;
     p.ok = p.strips >= 1 && p.rB - p.rT >= 8;
 }
+
+int launch_fused2_interior(ds_handle *h);
 
 int fused2_step(ds_handle *h)
 {
@@ -460,7 +467,21 @@ int fused2_step(ds_handle *h)
         return r;
     });
     if (rc != DS_OK) return rc;
-    // the interior: X -> Z, both iterations on chip
+    rc = launch_fused2_interior(h);
+    if (rc == DS_OK) rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
+    if (rc != DS_OK) return rc;
+    for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
+    h->fused_pending = true;
+    return DS_OK;
+}
+
+// The two-iteration kernel over the handle's interior: current second-colour planes -> the
+// alternate set, on the handle's stream.
+int launch_fused2_interior(ds_handle *h)
+{
+    ds::Geometry &g = h->g;
+    const ds_handle::Fused2Plan &p = h->plan2;
+    const long long *Z = h->alt_off;
     const int rows = p.rB - p.rT;
     int per_seg = 96;
     if (const char *e = std::getenv("DS_FUSED2_ROWS")) per_seg = std::atoi(e) > 0 ? std::atoi(e) : per_seg;  // tuning knob
@@ -496,10 +517,6 @@ int fused2_step(ds_handle *h)
         HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n + 1], h->stream));
         ++h->prof_n;
     }
-    rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
-    if (rc != DS_OK) return rc;
-    for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
-    h->fused_pending = true;
     return DS_OK;
 }
 

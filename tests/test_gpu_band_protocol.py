@@ -54,10 +54,12 @@ def _gloo_worker(rank, world, port, dtype, D, H, W, out):
         runner.iterate(iters)
         runner.iterate(0)
         runner.iterate(1)
+        runner.iterate(6)   # bands with an interior: two two-iteration steps + two single iterations
         energy = runner.energy()
+        steps = g.fused2_info()["steps"]
         whole = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
         whole.set_phi(phi0)
-        whole.iterate(iters + 1)
+        whole.iterate(iters + 7)
         same = np.array_equal(g.get_phi(), whole.get_phi()[rb:re])
         e_ref = whole.energy()
         e_ok = abs(energy - e_ref) <= 1e-9 * max(1.0, abs(e_ref))
@@ -69,7 +71,7 @@ def _gloo_worker(rank, world, port, dtype, D, H, W, out):
                 and np.array_equal(got["labels"], want["labels"][rb:re]) and got["not_empty"] == want["not_empty"]
         if not (same and e_ok and co_ok):
             print("rank", rank, "phi same:", same, "energy", energy, "ref", e_ref, "crossing-out", co_ok, flush=True)
-        out[rank] = (bool(same), bool(e_ok), bool(co_ok))
+        out[rank] = (bool(same), bool(e_ok), bool(co_ok), steps)
         g.close()
         whole.close()
     finally:
@@ -78,27 +80,39 @@ def _gloo_worker(rank, world, port, dtype, D, H, W, out):
 
 @pytest.mark.parametrize("world,dtype,D,H,W", [(2, "f32", 24, 13, 45), (3, "f64", 24, 13, 45), (2, "f32", 256, 29, 75),
                                                (3, "f64", 140, 29, 75), (2, "f64", 64, 17, 130), (3, "f32", 100, 40, 33),
-                                               (3, "f32", 64, 23, 70), (4, "f64", 40, 33, 52)])
+                                               (3, "f32", 64, 23, 70), (4, "f64", 40, 33, 52),
+                                               (3, "f32", 64, 60, 330), (2, "f32", 128, 41, 420), (2, "f32", 256, 36, 330),
+                                               (3, "f32", 64, 50, 330)])
 def test_ranks_sharing_one_gpu(world, dtype, D, H, W):
     """H = 13: bands of 4-7 rows sweep colour by colour; H = 29 and more: bands of 8 rows or more
     run the fused kernel in their interior; H = 23 over three ranks (8, 8, 7 rows) and H = 33 over
-    four (9, 8, 8, 8) put both kinds next to each other."""
+    four (9, 8, 8, 8) put both kinds next to each other.  The four wide f32 cases have bands with an
+    interior for the two-iteration kernel (D = 64 / 128 / 256: four, two and one pixel per wavefront)."""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_gloo_worker, args=(world, _free_port(), dtype, D, H, W, out), nprocs=world, join=True)
     for rank in range(world):
-        assert out[rank] == (True, True, True), "rank %d: %s" % (rank, out[rank])
+        assert out[rank][:3] == (True, True, True), "rank %d: %s" % (rank, out[rank])
+    # f32 bands of 14 rows or more, wide enough for a strip of the two-iteration kernel, step by two
+    # (3 steps over the calls of 3 + 0 + 1 + 6 iterations); H = 50 over three ranks (17, 17, 16 rows)
+    # has every rank on it, next to bands that are not in the other cases
+    steps = [out[rank][3] for rank in range(world)]
+    assert all(k in (0, 3) for k in steps)
+    if W >= 330 and dtype == "f32":
+        assert steps == [3] * world, steps
+    else:
+        assert steps == [0] * world, steps
 
 
-def _rccl_worker(rank, dtype, D, rows, out):
+def _rccl_worker(rank, dtype, D, rows, W, out):
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(240, exit=True, file=sys.stderr)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     load_package()
     from stereo_vision_amd import bands, diffstereo
-    H, W, iters = 40, 96, 3
+    H, iters = 40, 5 if W >= 330 else 3   # the wide band steps by two iterations twice, then one
     rb, re = rows
     left, right = random_pair(H, W, seed=12)
     phi0 = random_phi(H, W, D, dtype, seed=6)
@@ -126,19 +140,22 @@ def _rccl_worker(rank, dtype, D, rows, out):
     same = (np.array_equal(pa[1:-1], pb[1:-1]) and np.array_equal(pa[0, :, 3], pb[0, :, 3])
             and np.array_equal(pa[-1, :, 1], pb[-1, :, 1]))
     moved = not np.array_equal(pa[0], phi0[rb - 1].astype(pa.dtype))
-    out[0] = (bool(same), bool(moved), a.checksum() == b.checksum(), e_a == b.energy())
+    stepped = a.fused2_info()["steps"] == (2 if W >= 330 else 0)
+    out[0] = (bool(same), bool(moved), a.checksum() == b.checksum(), e_a == b.energy() and stepped)
     a.close()
     b.close()
     comm.close()
 
 
-@pytest.mark.parametrize("dtype,D,rows", [("f32", 64, (13, 29)), ("f64", 64, (13, 29)), ("f32", 200, (13, 29)),
-                                          ("f64", 130, (13, 29)), ("f32", 256, (20, 26))])
-def test_rccl_self_exchange_matches_device_copies(dtype, D, rows):
+@pytest.mark.parametrize("dtype,D,rows,W", [("f32", 64, (13, 29), 96), ("f64", 64, (13, 29), 96), ("f32", 200, (13, 29), 96),
+                                            ("f64", 130, (13, 29), 96), ("f32", 256, (20, 26), 96),
+                                            ("f32", 64, (9, 31), 330)])
+def test_rccl_self_exchange_matches_device_copies(dtype, D, rows, W):
     """16-row bands: interior in the fused kernel, boundary rows by half-sweeps on the boundary
-    stream, both exchanges per iteration over RCCL; the 6-row band sweeps colour by colour."""
+    stream, both exchanges per iteration over RCCL; the 6-row band sweeps colour by colour; the
+    330-column band steps by two iterations (four exchanges per step)."""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_rccl_worker, args=(dtype, D, rows, out), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(dtype, D, rows, W, out), nprocs=1, join=True)
     assert out[0] == (True, True, True, True), out[0]

@@ -24,13 +24,14 @@ comm = bands.RcclComm(0, 1, 0)
 runner = bands.Bands(g, comm, 0, 1, up=0 if rb > 0 else -1, down=0 if re < H else -1)
 runner.iterate(3)
 n = int(os.environ.get("N", 50))
-g.profile_begin(8 * n + 8)
+g.profile_begin(12 * n + 8)
 t0 = time.perf_counter()
 runner.iterate(n)
 wall = time.perf_counter() - t0
 g.profile_end()
 print("band %d of %d (rows %d-%d), %s: %.3f ms per iteration over RCCL loopback" % (which, n_bands, rb, re, dtype, wall / n * 1e3))
-for kind, name in ((0, "boundary half-sweeps"), (1, "interior kernel")):
+print("  two-iteration steps:", g.fused2_info())
+for kind, name in ((0, "boundary half-sweeps"), (1, "one-iteration launches"), (2, "two-iteration launches")):
     k, ms = g.profile_kind(kind)
     print("  %-22s %4d launches, %.3f ms per iteration" % (name, k, ms / n))
 g.close()
