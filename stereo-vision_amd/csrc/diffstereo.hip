@@ -483,9 +483,28 @@ int launch_fused2_interior(ds_handle *h)
     const ds_handle::Fused2Plan &p = h->plan2;
     const long long *Z = h->alt_off;
     const int rows = p.rB - p.rT;
-    int per_seg = 96;
-    if (const char *e = std::getenv("DS_FUSED2_ROWS")) per_seg = std::atoi(e) > 0 ? std::atoi(e) : per_seg;  // tuning knob
-    int segs = (rows + per_seg - 1) / per_seg;
+    // Row segments: about 96 rows each (a segment recomputes five rows of the first stages).  One
+    // block fills a CU (161 registers x 12 wavefronts), so the grid runs in rounds of cu_count
+    // blocks; when that leaves only a few rounds (a band: 264 rows of 4K x 256 have 198 strips, 3
+    // segments are 594 blocks = 3 rounds of 93 rows, 5 segments 990 blocks = 4 rounds of 58:
+    // 0.69 against 0.64 ms per iteration) take the number of segments that minimises
+    // rounds x (rows per segment + 5) among those that leave no CU without a block.
+    int segs = (rows + 95) / 96;
+    if ((long long)p.strips * segs < 4ll * h->cu_count) {
+        long long best = -1;
+        for (int k = 1; k <= (rows + 15) / 16; ++k) {
+            const int per = (rows + k - 1) / k;
+            const long long blocks = (long long)p.strips * ((rows + per - 1) / per);
+            if (blocks < h->cu_count && k < (rows + 15) / 16) continue;
+            const long long cost = ((blocks + h->cu_count - 1) / h->cu_count) * (per + 5);
+            if (best < 0 || cost < best) {
+                best = cost;
+                segs = k;
+            }
+        }
+    }
+    if (const char *e = std::getenv("DS_FUSED2_ROWS"))  // tuning knob: rows per segment
+        if (std::atoi(e) > 0) segs = (rows + std::atoi(e) - 1) / std::atoi(e);
     const int rows_per_seg = (rows + segs - 1) / segs;
     segs = (rows + rows_per_seg - 1) / rows_per_seg;
     const bool timed = h->prof && h->prof_n < h->prof_cap;
