@@ -190,11 +190,15 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
  * phi they were made from: pixels in raster order; each keeps, of its alive labels, the one with
  * the smallest f_t(d) (f64, the first of equals), its other labels are crossed out and the masks
  * are relaxed to their fixed point again (at most max_passes passes each time) before the next
- * pixel is looked at.  labels: [H][W].  *not_empty = 0 where the reference panics ("Graph is
- * empty", or a pixel without labels): labels of the pixels after that one are then not
- * meaningful.  *choices (optional) = pixels that still had more than one label when their turn
- * came.  Sequential by definition: one small launch per such pixel plus its relaxation passes;
- * pixels with one label left are walked through on the device.  Whole-image handles only. */
+ * pixel is looked at.  labels: [H][W], the one label each pixel has left at the end.
+ * *not_empty = 0 where the reference panics ("Graph is empty", or a pixel without labels): the
+ * labels are then not meaningful (0xffffffff at pixels without labels).  *choices (optional) =
+ * pixels that still had more than one label when their turn came.  Sequential by definition,
+ * but only over the pixels that have several labels when the call starts (masks only shrink,
+ * so no other pixel can have a choice later): one small launch per such pixel, and after a
+ * choice relaxation passes over a window that grows by one pixel per pass around it -- the
+ * same masks as whole-image passes, since a deletion can only follow one at a neighbour.
+ * Whole-image handles only. */
 int ds_find_best_labeling(ds_handle *h, int max_passes, uint32_t *labels, int *not_empty, long long *choices);
 
 /* Replaces create_array_of_epsilons before its tolerance dedup

@@ -1530,19 +1530,34 @@ int ds_co_begin(ds_handle *h, double epsilon)
     return DS_OK;
 }
 
-// One relaxation pass over the band, queued on the handle's stream; the two flags (a vertex
-// died / a pixel has no vertex left) end up in h->co_flags on the device.
-static int co_launch_pass(ds_handle *h)
+// One relaxation pass, queued on the handle's stream; the two flags (a vertex died / a pixel
+// has no vertex left) end up in h->co_flags on the device.  The pass covers the band, or, with
+// radius >= 0, the window of pixels within `radius` rows and columns of pixel (wi, wj) (rounded
+// out to whole blocks).
+static int co_launch_pass(ds_handle *h, int radius = -1, int wi = 0, int wj = 0)
 {
     const ds::Geometry &g = h->g;
-    const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
+    int row_first = g.row0, rows = g.Hb, seg_first = 0, segs = h->grid_x, col_lo = 0, col_hi = g.W - 1;
+    if (radius >= 0) {
+        const int r0 = wi - radius > g.row0 ? wi - radius : g.row0;
+        const int r1 = wi + radius < g.row0 + g.Hb - 1 ? wi + radius : g.row0 + g.Hb - 1;
+        const int c0 = wj - radius > 0 ? wj - radius : 0, c1 = wj + radius < g.W - 1 ? wj + radius : g.W - 1;
+        row_first = r0;
+        rows = r1 - r0 + 1;
+        col_lo = c0;
+        col_hi = c1;
+        seg_first = (c0 >> 1) / h->seg_pixels;
+        segs = (c1 >> 1) / h->seg_pixels - seg_first + 1;
+    }
+    const dim3 grid(segs, rows), block(ds::kBlock);
     HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
     for (int colour = 0; colour < 2; ++colour) {
         int rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
             hipLaunchKernelGGL((ds::co_relax_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
                                static_cast<const T *>(h->phi), (T)h->lambda, (T)h->co_epsilon, colour,
-                               h->seg_pixels, h->co_alive, static_cast<const T *>(h->co_gmin), h->co_flags);
+                               h->seg_pixels, h->co_alive, static_cast<const T *>(h->co_gmin), h->co_flags, row_first,
+                               seg_first, col_lo, col_hi);
             return DS_OK;
         });
         if (rc != DS_OK) return rc;
@@ -1664,33 +1679,62 @@ int ds_find_best_labeling(ds_handle *h, int max_passes, uint32_t *labels, int *n
         if (e != hipSuccess) return fail_hip(h, "hipMalloc(labeling state)", e);
     }
     const long long total = (long long)g.H * g.W;
-    long long next = 0, chosen = 0;
+    long long chosen = 0;
     int ok = 1;
-    while (next < total) {
-        // a launch walks at most 2^20 pixels, so that no single launch runs for seconds
+    const char *wenv = std::getenv("DS_LABELING_WINDOW");
+    const bool whole_passes = wenv && std::strcmp(wenv, "off") == 0;  // checking knob: whole-image passes
+    const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
+    // Masks only shrink, so the pixels that can still have a choice when their turn comes are among
+    // those with several labels now: count once, and visit only those, in raster order.
+    std::vector<uint32_t> counts((size_t)total);
+    for (int colour = 0; colour < 2; ++colour) {
+        switch (h->lpp) {
+        case 16: hipLaunchKernelGGL(ds::co_count_kernel<16>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels); break;
+        case 32: hipLaunchKernelGGL(ds::co_count_kernel<32>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels); break;
+        default: hipLaunchKernelGGL(ds::co_count_kernel<64>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels); break;
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipMemcpyAsync(counts.data(), h->d_labels, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (long long idx = 0; idx < total && ok; ++idx) {
+        if (counts[(size_t)idx] == 0) ok = 0;  // the reference's "Disparity ... wasn't found" at its first pixel without labels
+        if (counts[(size_t)idx] < 2 || !ok) continue;
+        // this pixel alone: one label left by now -> nothing to do; several -> the one with the
+        // smallest f_t(d) stays (co_fix_kernel)
         if (h->dtype == DS_F64)
             hipLaunchKernelGGL(ds::co_fix_kernel<double>, dim3(1), dim3(64), 0, h->stream, g,
-                               static_cast<const double *>(h->phi), h->cost_px, h->co_alive, next, 1LL << 20,
-                               h->d_labels, h->co_state);
+                               static_cast<const double *>(h->phi), h->cost_px, h->co_alive, idx, 1LL, h->d_labels,
+                               h->co_state);
         else
             hipLaunchKernelGGL(ds::co_fix_kernel<float>, dim3(1), dim3(64), 0, h->stream, g,
-                               static_cast<const float *>(h->phi), h->cost_px, h->co_alive, next, 1LL << 20,
-                               h->d_labels, h->co_state);
+                               static_cast<const float *>(h->phi), h->cost_px, h->co_alive, idx, 1LL, h->d_labels,
+                               h->co_state);
         HIPCHK(h, hipGetLastError());
         long long st[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(st, h->co_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        next = st[1];
-        if (st[0] == 2) {  // a pixel without labels: the reference's "Disparity ... wasn't found"
+        if (st[0] == 2) {  // no label left at this pixel
             ok = 0;
             break;
         }
         if (st[0] == 1) {  // labels were crossed out: back to the fixed point (crossing_out, :135-183)
             ++chosen;
+            // Only the chosen pixel's mask changed, and a deletion can only follow a deletion at a
+            // neighbour: pass k need not look further than k pixels from the chosen one (and changes
+            // nothing outside that window), and a pass that deletes nothing has reached the fixed
+            // point: no pixel beyond its window has a changed neighbour either.  The same masks as
+            // whole-image passes, at the cost of the window instead of the image.
+            const int pi = (int)(idx / g.W), pj = (int)(idx % g.W);
             int changed = 1, lost = 0, done = 0;
             while (changed && !lost && done < max_passes) {
-                rc = ds_co_pass(h, &changed, &lost);
+                rc = whole_passes ? co_launch_pass(h) : co_launch_pass(h, done + 1, pi, pj);
                 if (rc != DS_OK) return rc;
+                int flags[2] = {0, 0};
+                HIPCHK(h, hipMemcpyAsync(flags, h->co_flags, sizeof flags, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                changed = flags[0];
+                lost = flags[1];
                 ++done;
             }
             if (changed && !lost)
@@ -1700,6 +1744,16 @@ int ds_find_best_labeling(ds_handle *h, int max_passes, uint32_t *labels, int *n
                 break;
             }
         }
+    }
+    // every pixel has one label left (or the run ended early): the smallest alive label per pixel
+    HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
+    for (int colour = 0; colour < 2; ++colour) {
+        switch (h->lpp) {
+        case 16: hipLaunchKernelGGL(ds::co_labels_kernel<16>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels, h->co_flags + 1); break;
+        case 32: hipLaunchKernelGGL(ds::co_labels_kernel<32>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels, h->co_flags + 1); break;
+        default: hipLaunchKernelGGL(ds::co_labels_kernel<64>, grid, block, 0, h->stream, g, h->co_alive, colour, h->seg_pixels, h->d_labels, h->co_flags + 1); break;
+        }
+        HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipMemcpyAsync(labels, h->d_labels, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -1143,14 +1143,15 @@ template <typename T, int LPP>
 __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *__restrict__ phi, T lambda,
                                                           T eps, int colour, int seg_pixels,
                                                           uint8_t *alive, const T *__restrict__ gmin,
-                                                          int *__restrict__ changed)
+                                                          int *__restrict__ changed, int row_first, int seg_first,
+                                                          int col_lo, int col_hi)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP;
     const T inf = R::inf();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
-    const int i = g.row0 + blockIdx.y;
+    const int i = row_first + blockIdx.y;  // the grid may cover a window of the band only
     const int s = (i + colour) & 1;
     T lam[4];
 #pragma unroll
@@ -1159,7 +1160,7 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
     const uint8_t *alive_o = mask_base(g, alive, 1 - colour);
     const T *gmin_c = gmin + (long long)colour * g.Hb * g.Wh * 4;
 
-    const int seg0 = blockIdx.x * seg_pixels;
+    const int seg0 = (seg_first + blockIdx.x) * seg_pixels;
     const int groups = seg_pixels / PPW;
     bool any = false, lost = false;
     for (int grp = wave; grp < groups; grp += kBlock / 64) {
@@ -1194,6 +1195,10 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
                 if (p.has[n]) ok = ok && (own[n].v[k] + M[n].v[k] <= gm[n] + eps);
             if (!ok) next &= ~(1u << (8 * k));
         }
+        // a windowed pass changes nothing outside its window, however far its blocks reach: the
+        // caller's bookkeeping (which pixels can still be affected) counts on it
+        const bool inside = p.j >= col_lo && p.j <= col_hi;
+        if (!inside) next = mine;
         if (p.active && next != mine) {
             *reinterpret_cast<volatile uint32_t *>(alive_c + p.cost) = next;
             any = true;
@@ -1201,7 +1206,7 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
         uint32_t left_alive = p.active ? next : 0u;
 #pragma unroll
         for (int m = LPP / 2; m >= 1; m >>= 1) left_alive |= __shfl_xor(left_alive, m);
-        if (p.j < g.W && lseg == 0 && left_alive == 0u) lost = true;
+        if (p.j < g.W && inside && lseg == 0 && left_alive == 0u) lost = true;
     }
     if (__any(any) && lane == 0) atomicOr(changed, 1);
     if (__any(lost) && lane == 0) atomicOr(changed + 1, 1);
@@ -1239,6 +1244,30 @@ __global__ __launch_bounds__(kBlock) void co_labels_kernel(Geometry g, const uin
             out[(long long)(i - g.row0) * g.W + p.j] = first == 0x7fffffff ? 0xffffffffu : (uint32_t)first;
             if (first == 0x7fffffff) atomicOr(empty, 1);
         }
+    }
+}
+
+// Alive labels per pixel: out[row][j] = how many labels the pixel has left.
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void co_count_kernel(Geometry g, const uint8_t *__restrict__ alive, int colour,
+                                                          int seg_pixels, uint32_t *__restrict__ out)
+{
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int i = g.row0 + blockIdx.y;
+    const int s = (i + colour) & 1;
+    const uint8_t *alive_c = mask_base(g, alive, colour);
+    const int seg0 = blockIdx.x * seg_pixels;
+    const int groups = seg_pixels / PPW;
+    for (int grp = wave; grp < groups; grp += kBlock / 64) {
+        const int jc = seg0 + grp * PPW + q;
+        const Pixel p = locate(g, i, s, jc, d0);
+        const uint32_t bits = p.active ? *reinterpret_cast<const uint32_t *>(alive_c + p.cost) & 0x01010101u : 0u;
+        int count = __popc(bits);
+#pragma unroll
+        for (int m = LPP / 2; m >= 1; m >>= 1) count += __shfl_xor(count, m);
+        if (p.j < g.W && lseg == 0) out[(long long)(i - g.row0) * g.W + p.j] = (uint32_t)count;
     }
 }
 
