@@ -264,32 +264,50 @@ int band_fused2_step(ds_handle *h)
         const int n = colour == 0 ? 2 : 1;  // the first colour's two rows feed the second colour's one
         return launch_sweep(h, colour, rb, up ? rb + n : rb, &geo, down ? re - n : re, re);
     };
-    int rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
+    // Three queues beside each other.  Boundary stream: only what the four exchanges wait for or
+    // follow from.  Frame stream: the frame's launches, which read X and Y inside the band only;
+    // the two that make Y's rows next to the boundary rows come first, the boundary stream waits
+    // for them before it reads Y there.  Handle's stream: the interior.  Every launch of the step
+    // writes its own part of Y or Z; the step ends when all three have.
+    int rc = need_frame_stream(h);
+    if (rc == DS_OK) rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
+    if (rc == DS_OK) HIPCHK(h, hipStreamWaitEvent(h->frame_stream, h->ev_main, 0));
     if (rc != DS_OK) return rc;
-    rc = on_side_stream(h, [&]() -> int {
-        hipStream_t side = h->side_stream;
+    rc = on_stream(h, h->frame_stream, [&]() -> int {
         // iteration n + 1 on the widened frame: X -> Y
         int r = launch_fused_region(h, X, Y, 0, all, top0, p.rT + 2, 1);
         if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, all, p.rB - 2, bot1, 1);
-        if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2, 1);
+        if (r != DS_OK) return r;
+        HIPCHK(h, hipEventRecord(h->ev_rows, h->frame_stream));
+        r = launch_fused_region(h, X, Y, 0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2, 1);
         if (r == DS_OK) r = launch_fused_region(h, X, Y, right0, right_strips, p.rT + 2, p.rB - 2, 1);
-        if (r == DS_OK) r = sweep_boundary(0, X);
-        if (r == DS_OK) r = exchange_planes(h, g.plane_off[0], side);
-        if (r == DS_OK) r = sweep_boundary(1, Y);
-        if (r == DS_OK) r = exchange_planes(h, Y, side);
-        // iteration n + 2 on the frame: Y -> Z
-        if (r == DS_OK) r = sweep_boundary(0, Y);
-        if (r == DS_OK) r = exchange_planes(h, g.plane_off[0], side);
-        if (r == DS_OK) r = sweep_boundary(1, Z);
-        if (r == DS_OK) r = exchange_planes(h, Z, side);
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, top0, p.rT, 1);
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, p.rB, bot1, 1);
+        // iteration n + 2 on the frame's columns: Y -> Z (rows rT - 2 .. rB + 2 of Y: the launches above)
         if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, p.cL / p.strip1, p.rT, p.rB, 1);
         if (r == DS_OK) r = launch_fused_region(h, Y, Z, p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB, 1);
         return r;
     });
+    if (rc != DS_OK) return rc;
+    rc = on_side_stream(h, [&]() -> int {
+        hipStream_t side = h->side_stream;
+        int r = sweep_boundary(0, X);
+        if (r == DS_OK) r = exchange_planes(h, g.plane_off[0], side);
+        if (r == DS_OK) r = sweep_boundary(1, Y);
+        if (r == DS_OK) r = exchange_planes(h, Y, side);
+        // iteration n + 2: the first colour's boundary rows read Y's rows below / above them
+        if (r != DS_OK) return r;
+        HIPCHK(h, hipStreamWaitEvent(side, h->ev_rows, 0));
+        r = sweep_boundary(0, Y);
+        if (r == DS_OK) r = exchange_planes(h, g.plane_off[0], side);
+        if (r == DS_OK) r = sweep_boundary(1, Z);
+        if (r == DS_OK) r = exchange_planes(h, Z, side);
+        // the frame's rows, Y -> Z: they read Y's boundary and halo rows (second exchange)
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, top0, p.rT, 1);
+        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, p.rB, bot1, 1);
+        return r;
+    });
     if (rc == DS_OK) rc = launch_fused2_interior(h);
     if (rc == DS_OK) rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
+    if (rc == DS_OK) rc = order_streams(h, h->frame_stream, h->ev_frame, h->stream);
     if (rc != DS_OK) return rc;
     for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
     h->fused_pending = true;

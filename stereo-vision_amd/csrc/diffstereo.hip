@@ -106,6 +106,9 @@ struct ds_handle {
     int up = -1, down = -1;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    // a band's two-iteration step: the frame's launches that no exchange waits for
+    hipStream_t frame_stream = nullptr;
+    hipEvent_t ev_frame = nullptr, ev_rows = nullptr;
     int *d_flag = nullptr;  // one int on the device for the bands' agreement on not_empty
 
     bool prof = false;
@@ -234,6 +237,12 @@ void release(ds_handle *h)
         (void)hipStreamSynchronize(h->side_stream);
         (void)hipStreamDestroy(h->side_stream);
     }
+    if (h->frame_stream) {
+        (void)hipStreamSynchronize(h->frame_stream);
+        (void)hipStreamDestroy(h->frame_stream);
+    }
+    if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
+    if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     (void)hipFree(h->d_flag);
@@ -384,15 +393,16 @@ int order_streams(ds_handle *h, hipStream_t from, hipEvent_t ev, hipStream_t to)
     return DS_OK;
 }
 
-// Launches of the library go to h->stream: run `body` with the side stream in its place.
-template <typename F> int on_side_stream(ds_handle *h, F &&body)
+// Launches of the library go to h->stream: run `body` with another stream in its place.
+template <typename F> int on_stream(ds_handle *h, hipStream_t stream, F &&body)
 {
     hipStream_t keep = h->stream;
-    h->stream = h->side_stream;
+    h->stream = stream;
     const int rc = body();
     h->stream = keep;
     return rc;
 }
+template <typename F> int on_side_stream(ds_handle *h, F &&body) { return on_stream(h, h->side_stream, body); }
 
 // The second stream of a handle (a band's boundary rows, the borders of a two-iteration step)
 // and the two events that order it against the handle's stream.
@@ -401,6 +411,14 @@ int need_side_stream(ds_handle *h)
     if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     if (!h->ev_main) HIPCHK(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
     if (!h->ev_side) HIPCHK(h, hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+    return DS_OK;
+}
+
+int need_frame_stream(ds_handle *h)
+{
+    if (!h->frame_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->frame_stream, hipStreamNonBlocking));
+    if (!h->ev_frame) HIPCHK(h, hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
+    if (!h->ev_rows) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming));
     return DS_OK;
 }
 

@@ -144,6 +144,9 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
     const int kp = wave * PPW + q;
+    // the slots of this wavefront, as scalars: a stage skips a wavefront none of whose slots it
+    // needs (the strip narrows by one slot per stage), every wavefront still reaches the barrier
+    const int wave_first = __builtin_amdgcn_readfirstlane(wave) * PPW, wave_last = wave_first + PPW - 1;
     const int rev4 = 4 * (63 - lane);
     T lam[4];
 #pragma unroll
@@ -188,9 +191,9 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         pre_cost = cost_word(cost_red, r, j);
     };
     // messages kept in registers, named by the stage that made them and the row that uses them
-    V a_down_prev = splat(inf), a_down_cur = splat(inf), a_side_cur = splat(inf), a_down_next, a_side_next, a_up_next;
-    V b_down_prev = splat(inf), b_down_cur = splat(inf), b_side_cur = splat(inf), b_down_next, b_side_next, b_up_next;
-    V c_down_prev = splat(inf), c_down_cur = splat(inf), c_side_cur = splat(inf), c_down_next, c_side_next, c_up_next;
+    V a_down_prev = splat(inf), a_down_cur = splat(inf), a_side_cur = splat(inf), a_down_next = splat(inf), a_side_next = splat(inf), a_up_next = splat(inf);
+    V b_down_prev = splat(inf), b_down_cur = splat(inf), b_side_cur = splat(inf), b_down_next = splat(inf), b_side_next = splat(inf), b_up_next = splat(inf);
+    V c_down_prev = splat(inf), c_down_cur = splat(inf), c_side_cur = splat(inf), c_down_next = splat(inf), c_side_next = splat(inf), c_up_next = splat(inf);
 
     auto stage_a = [&](auto parity) {  // red of a row with parity P, iteration n+1
         constexpr int P = decltype(parity)::value;
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     auto stage_b = [&](int i, auto parity) {  // black(i), iteration n+1: stays on chip
         constexpr int P = decltype(parity)::value;
         const int j = P ? a + 1 : a;
+        if (P ? wave_first > NP - 2 : wave_last < 1) return;  // no stage uses this slot's black pixel of this row
         V psi[4], out[4];
         const V across = load4(&lds.ring1[P][P ? kr : kl][d0]);
         psi[0] = P ? a_side_cur : across;
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     auto stage_c = [&](int r, auto parity) {  // red(r), iteration n+2
         constexpr int P = decltype(parity)::value;
         const int j = P ? a : a + 1;
+        if (wave_last < 1 || wave_first > NP - 2) return;  // stage D takes nothing from the outermost slots
         V psi[4], out[4];
         const V across = load4(&lds.ring2[P][P ? kl : kr][d0]);
         psi[0] = P ? across : b_side_cur;
@@ -241,6 +246,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         constexpr int P = decltype(parity)::value;
         const int j = P ? a + 1 : a;
         const bool mine = P ? (kp >= 1 && kp <= NP - 3) : (kp >= 2 && kp <= NP - 2);
+        if (P ? (wave_last < 1 || wave_first > NP - 3) : (wave_last < 2 || wave_first > NP - 2)) return;
         V psi[4], out[4];
         const V across = load4(&lds.ring3[P][P ? kr : kl][d0]);
         psi[0] = P ? c_side_cur : across;
