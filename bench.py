@@ -328,7 +328,9 @@ def main():
             bytes_per_pl = 4 * elem + 2
             kernel = "ds::fused2_iteration_kernel<%s, %d, 12>" % (tname, lpp)
             kernel_s, launches = ms2 / 1e3, n2
-            units_per_launch = (f2["cols"][1] - f2["cols"][0]) * (f2["rows"][1] - f2["rows"][0]) * D
+            # valid (pixel, label) pairs of the interior region: column j has min(j, D - 1) + 1 labels
+            units_per_launch = (sum(min(j, D - 1) + 1 for j in range(f2["cols"][0], f2["cols"][1]))
+                                * (f2["rows"][1] - f2["rows"][0]))
             note = ("one launch = TWO iterations over the image's interior (columns %d-%d, rows %d-%d); it moves "
                     "(4*sizeof(T)+2)/2 B per valid pixel*label*iteration and is bound by the vector ALU, not by "
                     "HBM: frac is what the metric asks for (algorithmic bytes / time / HBM peak), "

@@ -97,10 +97,7 @@ class GlooTransport:
         self.group, self.device, self.error = group, device, None
         self.name = "gloo through host memory"
         if device:
-            hip = C.CDLL("libamdhip64.so")
-            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-            self._hip = hip
+            self._hip = diffstereo.hip_runtime()
         self._keep = (diffstereo.EXCHANGE_FN(self._exchange), diffstereo.ALL_REDUCE_FN(self._all_reduce))
         self.struct = diffstereo.TransportStruct(None, self._keep[0], self._keep[1], diffstereo.LAST_ERROR_FN())
 

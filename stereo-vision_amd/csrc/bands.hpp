@@ -275,15 +275,17 @@ int band_fused2_step(ds_handle *h)
     if (rc != DS_OK) return rc;
     rc = on_stream(h, h->frame_stream, [&]() -> int {
         // iteration n + 1 on the widened frame: X -> Y
-        int r = launch_fused_region(h, X, Y, 0, all, top0, p.rT + 2, 1);
-        if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, all, p.rB - 2, bot1, 1);
+        const FrameRegion rows1[2] = {{0, all, top0, p.rT + 2}, {0, all, p.rB - 2, bot1}};
+        const FrameRegion cols1[2] = {{0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2},
+                                      {right0, right_strips, p.rT + 2, p.rB - 2}};
+        // iteration n + 2 on the frame's columns: Y -> Z (rows rT - 2 .. rB + 2 of Y: the launches above)
+        const FrameRegion cols2[2] = {{0, p.cL / p.strip1, p.rT, p.rB},
+                                      {p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB}};
+        int r = launch_fused_regions(h, X, Y, rows1, 2, 1);
         if (r != DS_OK) return r;
         HIPCHK(h, hipEventRecord(h->ev_rows, h->frame_stream));
-        r = launch_fused_region(h, X, Y, 0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2, 1);
-        if (r == DS_OK) r = launch_fused_region(h, X, Y, right0, right_strips, p.rT + 2, p.rB - 2, 1);
-        // iteration n + 2 on the frame's columns: Y -> Z (rows rT - 2 .. rB + 2 of Y: the launches above)
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, p.cL / p.strip1, p.rT, p.rB, 1);
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB, 1);
+        r = launch_fused_regions(h, X, Y, cols1, 2, 1);
+        if (r == DS_OK) r = launch_fused_regions(h, Y, Z, cols2, 2, 1);
         return r;
     });
     if (rc != DS_OK) return rc;
@@ -301,8 +303,8 @@ int band_fused2_step(ds_handle *h)
         if (r == DS_OK) r = sweep_boundary(1, Z);
         if (r == DS_OK) r = exchange_planes(h, Z, side);
         // the frame's rows, Y -> Z: they read Y's boundary and halo rows (second exchange)
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, top0, p.rT, 1);
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, p.rB, bot1, 1);
+        const FrameRegion rows2[2] = {{0, all, top0, p.rT}, {0, all, p.rB, bot1}};
+        if (r == DS_OK) r = launch_fused_regions(h, Y, Z, rows2, 2, 1);
         return r;
     });
     if (rc == DS_OK) rc = launch_fused2_interior(h);

@@ -301,6 +301,24 @@ void fused_safe_rows(const ds_handle *h, int *begin, int *end)
     *end = g.row0 + g.Hb == g.H ? g.H : g.row0 + g.Hb - 1;
 }
 
+// Row segments of a one-iteration launch.  One or two blocks fill a CU's LDS, so the grid runs in
+// rounds; many short blocks even out the slower border strips and whatever CUs a concurrent
+// transfer kernel holds, and a segment only costs the two extra red rows it recomputes.  Measured
+// with 16-wavefront blocks, 4K x 256 f32, ms per iteration for 4 / 8 / 16 / 32 / 48 segments of the
+// 2160 rows: 8.25 / 7.85 / 7.17 / 6.77 / 6.76; a 270-row band next to RCCL traffic: 1.12 ms with
+// 2..8 segments, 1.07 with 12.  So: about 64 rows per segment, but at least 6 blocks per CU.
+int fused_rows_per_segment(const ds_handle *h, int strips, int rows)
+{
+    int segs = (rows + 63) / 64;
+    const int want = (6 * h->cu_count + strips - 1) / strips;
+    if (segs < want) segs = want;
+    if (segs > (rows + 15) / 16) segs = (rows + 15) / 16;
+    if (segs < 1) segs = 1;
+    if (const char *e = std::getenv("DS_FUSED_SEGMENTS")) segs = std::atoi(e) > 0 ? std::atoi(e) : segs;  // tuning knob
+    if (segs > rows) segs = rows;
+    return (rows + segs - 1) / segs;
+}
+
 // The one-iteration kernel over the colour-1 rows [row_begin, row_end) and `strips` column
 // strips from column col_begin (even) on: reads the colour-1 planes `in_off`, writes `out_off`
 // (element offsets from the phi base).  kind: how the launch is booked by ds_profile_*.
@@ -317,22 +335,7 @@ int launch_fused_region(ds_handle *h, const long long in_off[4], const long long
         h->prof_kind[h->prof_n] = kind;
     }
     const int fw = h->fused_waves;
-    // Row segments.  One or two blocks fill a CU's LDS, so the grid runs in rounds; many short
-    // blocks even out the slower border strips and whatever CUs a concurrent transfer kernel
-    // holds, and a segment only costs the two extra red rows it recomputes.  Measured with
-    // 16-wavefront blocks, 4K x 256 f32, ms per iteration for 4 / 8 / 16 / 32 / 48 segments of the
-    // 2160 rows: 8.25 / 7.85 / 7.17 / 6.77 / 6.76; a 270-row band next to RCCL traffic: 1.12 ms with
-    // 2..8 segments, 1.07 with 12.  So: about 64 rows per segment, but at least 6 blocks per CU.
-    int segs = (rows + 63) / 64;
-    {
-        const int want = (6 * h->cu_count + strips - 1) / strips;
-        if (segs < want) segs = want;
-        if (segs > (rows + 15) / 16) segs = (rows + 15) / 16;
-        if (segs < 1) segs = 1;
-    }
-    if (const char *e = std::getenv("DS_FUSED_SEGMENTS")) segs = std::atoi(e) > 0 ? std::atoi(e) : segs;  // tuning knob
-    if (segs > rows) segs = rows;
-    const int rows_per_seg = (rows + segs - 1) / segs;
+    const int rows_per_seg = fused_rows_per_segment(h, strips, rows);
     const dim3 grid(strips, (rows + rows_per_seg - 1) / rows_per_seg), block(64 * fw);
     ds::FusedPlanes np;
     for (int s = 0; s < 4; ++s) np.out_off[s] = out_off[s];
@@ -349,6 +352,65 @@ int launch_fused_region(ds_handle *h, const long long in_off[4], const long long
                 hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, false>), grid, block, 0, h->stream, geo,
                                    static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end,
                                    rows_per_seg, col_begin);
+        };
+        if (fw == 16) go(std::integral_constant<int, 16>{});
+        else if (fw == 8) go(std::integral_constant<int, 8>{});
+        else go(std::integral_constant<int, 4>{});
+        return DS_OK;
+    });
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipGetLastError());
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n + 1], h->stream));
+        ++h->prof_n;
+    }
+    return DS_OK;
+}
+
+// Several regions of the same planes in one launch (empty ones are left out).
+struct FrameRegion {
+    int col_begin, strips, row_begin, row_end;
+};
+
+int launch_fused_regions(ds_handle *h, const long long in_off[4], const long long out_off[4], const FrameRegion *regions,
+                         int count, int kind)
+{
+    ds::FusedRegions reg{};
+    int blocks = 0;
+    for (int k = 0; k < count && reg.n < 4; ++k) {
+        const FrameRegion &r = regions[k];
+        const int rows = r.row_end - r.row_begin;
+        if (rows <= 0 || r.strips <= 0) continue;
+        const int per = fused_rows_per_segment(h, r.strips, rows);
+        const int n = reg.n++;
+        reg.first[n] = blocks;
+        reg.col_begin[n] = r.col_begin;
+        reg.strips[n] = r.strips;
+        reg.row_begin[n] = r.row_begin;
+        reg.row_end[n] = r.row_end;
+        reg.rows_per_seg[n] = per;
+        blocks += r.strips * ((rows + per - 1) / per);
+    }
+    if (reg.n == 0) return DS_OK;
+    reg.first[reg.n] = blocks;
+    ds::Geometry geo = h->g;
+    for (int s = 0; s < 4; ++s) geo.plane_off[1][s] = in_off[s];
+    const bool timed = h->prof && h->prof_n < h->prof_cap;
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
+        h->prof_kind[h->prof_n] = kind;
+    }
+    const int fw = h->fused_waves;
+    const dim3 grid(blocks), block(64 * fw);
+    ds::FusedPlanes np;
+    for (int s = 0; s < 4; ++s) np.out_off[s] = out_off[s];
+    int rc = dispatch(h, [&](auto t, auto lpp) -> int {
+        using T = decltype(t);
+        constexpr int L = decltype(lpp)::value;
+        auto go = [&](auto fwc) {
+            constexpr int FW = decltype(fwc)::value;
+            hipLaunchKernelGGL((ds::fused_regions_kernel<T, L, FW>), grid, block, 0, h->stream, geo,
+                               static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, reg);
         };
         if (fw == 16) go(std::integral_constant<int, 16>{});
         else if (fw == 8) go(std::integral_constant<int, 8>{});
@@ -446,7 +508,14 @@ void plan_fused2(ds_handle *h)
     if (const char *w = std::getenv("DS_F2_WAVES")) p.waves = std::atoi(w) == 16 ? 16 : 12;  // tuning knob
     const int FC1 = 2 * (16 * (64 / h->lpp) - 1);                 // the one-iteration kernel's strip
     const int NP = p.waves * (64 / h->lpp), FC2 = 2 * (NP - 3);   // the two-iteration kernel's slots and strip
-    p.cL = ((g.D + 3 + FC1 - 1) / FC1) * FC1;  // a multiple of the one-iteration strip; c0 - 1 = cL - 3 >= D
+    // Left edge: a multiple of the one-iteration strip.  One strip is enough for every pixel the
+    // kernel touches to have a left neighbour (c0 - 2 = cL - 4 >= 0); DS_FUSED2_LEFT=full keeps
+    // the kernel to the columns where every label exists (c0 - 1 = cL - 3 >= D), for checking.
+    p.cL = FC1;
+    if (const char *l = std::getenv("DS_FUSED2_LEFT")) {
+        if (std::strcmp(l, "full") == 0) p.cL = ((g.D + 3 + FC1 - 1) / FC1) * FC1;
+        else if (std::atoi(l) > 0) p.cL = ((std::atoi(l) + FC1 - 1) / FC1) * FC1;  // tuning knob: columns left to the one-iteration kernel
+    }
     const long long room = (long long)g.W - 1 - 2 * NP - (p.cL - 2);  // c0 of the last strip + 2 NP < W
     p.strips = room >= 0 ? (int)(room / FC2) + 1 : 0;
     p.cR = p.cL + p.strips * FC2;
@@ -470,18 +539,20 @@ int fused2_step(ds_handle *h)
     int rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
     if (rc != DS_OK) return rc;
     rc = on_side_stream(h, [&]() -> int {
-        // first iteration on the widened frame: X -> Y
-        int r = launch_fused_region(h, X, Y, 0, all, 0, p.rT + 2, 1);
-        if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, all, p.rB - 2, g.H, 1);
-        if (r == DS_OK) r = launch_fused_region(h, X, Y, 0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2, 1);
-        if (r == DS_OK)
-            r = launch_fused_region(h, X, Y, p.cR - p.strip1, (g.W - (p.cR - p.strip1) + p.strip1 - 1) / p.strip1,
-                                    p.rT + 2, p.rB - 2, 1);
-        // second iteration on the frame: Y -> Z
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, 0, p.rT, 1);
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, all, p.rB, g.H, 1);
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, 0, p.cL / p.strip1, p.rT, p.rB, 1);
-        if (r == DS_OK) r = launch_fused_region(h, Y, Z, p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB, 1);
+        const int right0 = p.cR - p.strip1;
+        // first iteration on the widened frame, X -> Y; second iteration on the frame, Y -> Z: one
+        // launch each (a stream of eight small dependent launches beside a kernel that fills the
+        // device gets compute units only as that kernel's blocks end, launch after launch)
+        const FrameRegion first[4] = {{0, all, 0, p.rT + 2},
+                                      {0, all, p.rB - 2, g.H},
+                                      {0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2},
+                                      {right0, (g.W - right0 + p.strip1 - 1) / p.strip1, p.rT + 2, p.rB - 2}};
+        const FrameRegion second[4] = {{0, all, 0, p.rT},
+                                       {0, all, p.rB, g.H},
+                                       {0, p.cL / p.strip1, p.rT, p.rB},
+                                       {p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB}};
+        int r = launch_fused_regions(h, X, Y, first, 4, 1);
+        if (r == DS_OK) r = launch_fused_regions(h, Y, Z, second, 4, 1);
         return r;
     });
     if (rc != DS_OK) return rc;

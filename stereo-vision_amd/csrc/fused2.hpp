@@ -16,11 +16,10 @@
 // NP, B NP - 1, C NP - 2, D NP - 3): a strip of FC2 = 2 (NP - 3) output columns whose first is
 // c0 + 2, c0 = col_begin - 2 + blockIdx.x * FC2, reads columns c0 - 2 .. c0 + 2 NP.
 //
-// Only blocks in which every pixel any stage touches has four neighbours and all D labels
-// (D = 4 LPP): the host launches it over that interior and gives the rest of the image to the
-// one-iteration kernel, twice (launch_fused2 in diffstereo.hip).  The arithmetic per pixel is the
-// one-iteration kernel's interior path, operation for operation, so the results are the same
-// bits.
+// Only blocks in which every pixel any stage touches has four neighbours (D = 4 LPP): the host
+// launches it over that interior and gives the rest of the image to the one-iteration kernel,
+// twice (launch_fused2 in diffstereo.hip).  The arithmetic per pixel is the one-iteration
+// kernel's, operation for operation, so the results are the same bits.
 //
 // The row loop is unrolled by two so that the row's parity (which of a slot's two columns holds
 // the red pixel) is a compile-time constant: no selects between "own side" and "across".
@@ -159,7 +158,12 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     const int kl = kp > 0 ? kp - 1 : 0, kr = kp < NP - 1 ? kp + 1 : NP - 1;  // neighbouring slots (clamped: the
                                                                               // strip's outermost slots are not kept)
     using V = V4<T>;
-    auto update = [&](const V psi[4], uint32_t cost_word, V out[4]) {
+    // Strips left of column D: the pixel in column j has the labels d <= j only.  The arithmetic
+    // is the same (the labels that do not exist hold +inf in memory and drop out of every
+    // minimum); only the results for such labels are put back to +inf (the sums above them may be
+    // inf - inf).  One scalar branch per update for the other strips.
+    const bool few_labels = c0 - 1 < g.D;
+    auto update = [&](const V psi[4], uint32_t cost_word, int j, V out[4]) {
         V M[4];
         const V qc = unpack_cost<T>(cost_word);
         if constexpr (sizeof(T) == 4) messages_lean<LPP>(psi, lam, lambda, lseg, rev4, M);
@@ -169,6 +173,14 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
             const T avg = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * T(0.25);
 #pragma unroll
             for (int n = 0; n < 4; ++n) out[n].v[c] = avg - M[n].v[c];
+        }
+        if (few_labels) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool valid = d0 + c <= j;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) out[n].v[c] = valid ? out[n].v[c] : inf;
+            }
         }
     };
     auto cost_word = [&](const uint8_t *base, int row, int j) {
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         V psi[4], out[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) psi[n] = pre_psi[n];
-        update(psi, pre_cost, out);
+        update(psi, pre_cost, P ? a : a + 1, out);
         // odd row: red at a, its right neighbour is the slot's own black pixel, its left one the
         // previous slot's; even row: mirrored
         store4(&lds.ring1[P][kp][d0], P ? out[0] : out[2]);
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         psi[1] = a_down_prev;
         psi[2] = P ? across : a_side_cur;
         psi[3] = a_up_next;
-        update(psi, cost_word(cost_black, i, j), out);
+        update(psi, cost_word(cost_black, i, j), j, out);
         // odd row: black at a + 1, its left neighbour is the slot's own red pixel, its right one the
         // next slot's
         store4(&lds.ring2[P][kp][d0], P ? out[2] : out[0]);
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         psi[1] = b_down_prev;
         psi[2] = P ? b_side_cur : across;
         psi[3] = b_up_next;
-        update(psi, cost_word(cost_red, r, j), out);
+        update(psi, cost_word(cost_red, r, j), j, out);
         store4(&lds.ring3[P][kp][d0], P ? out[0] : out[2]);
         c_side_next = P ? out[2] : out[0];
         c_up_next = out[1];
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         psi[1] = c_down_prev;
         psi[2] = P ? across : c_side_cur;
         psi[3] = c_up_next;
-        update(psi, cost_word(cost_black, i, j), out);
+        update(psi, cost_word(cost_black, i, j), j, out);
         if (mine) {
             const long long own = (long long)(i - g.row0 + 1) * g.row_stride + (long long)(j >> 1) * g.Dpad + d0;
 #pragma unroll

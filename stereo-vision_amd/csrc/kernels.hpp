@@ -639,12 +639,12 @@ template <typename T, int NP, int DL> struct FusedLds {
     T h[2][NP][DL];
 };
 
-// PROBE only changes the kernel's name (placement probes at ds_create, as for sweep_kernel).
-template <typename T, int LPP, int FW, bool PROBE = false>
-__global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
-                                                                  const uint8_t *__restrict__ cost, T lambda,
-                                                                  int row_begin, int row_end, int rows_per_seg,
-                                                                  int col_begin)
+// The work of one block: strip `strip` (from column col_begin on) x row segment `seg` (from
+// row_begin on) of the launch's region.
+template <typename T, int LPP, int FW>
+__device__ __forceinline__ void fused_iteration_block(const Geometry &g, T *__restrict__ phi, const FusedPlanes &np,
+                                                      const uint8_t *__restrict__ cost, T lambda, int row_begin,
+                                                      int row_end, int rows_per_seg, int col_begin, int strip, int seg)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP, NP = FW * PPW, NB = NP - 1, FC = 2 * NB, DL = 4 * LPP;
@@ -656,9 +656,9 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
     T lam[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
-    const int c0 = col_begin + blockIdx.x * FC;  // col_begin even: strips may start anywhere (launches over a part of the image)
+    const int c0 = col_begin + strip * FC;  // col_begin even: strips may start anywhere (launches over a part of the image)
     const int a = c0 - 1 + 2 * kp;  // first column of the slot's pair (odd)
-    const int r0 = row_begin + blockIdx.y * rows_per_seg;
+    const int r0 = row_begin + seg * rows_per_seg;
     const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
     const bool cols_interior = g.D == DL && c0 - 1 >= g.D && c0 + FC + 1 < g.W;
     const uint8_t *cost_red = cost, *cost_black = cost + g.cost_colour_stride;
@@ -818,6 +818,42 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
         rotate();
         __syncthreads();
     }
+}
+
+// One rectangular region per launch: grid (strips, row segments).
+// PROBE only changes the kernel's name (placement probes at ds_create, as for sweep_kernel).
+template <typename T, int LPP, int FW, bool PROBE = false>
+__global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
+                                                                  const uint8_t *__restrict__ cost, T lambda,
+                                                                  int row_begin, int row_end, int rows_per_seg,
+                                                                  int col_begin)
+{
+    fused_iteration_block<T, LPP, FW>(g, phi, np, cost, lambda, row_begin, row_end, rows_per_seg, col_begin,
+                                      (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Up to four rectangular regions in one launch (the frame around a two-iteration step's interior:
+// dependent launches on a stream that shares the device with a kernel that fills it each wait
+// for compute units to drain, so fewer, larger launches finish earlier).  Grid: first[n] blocks
+// in one dimension; block b belongs to the region k with first[k] <= b < first[k + 1], strip
+// (b - first[k]) % strips[k], row segment (b - first[k]) / strips[k].
+struct FusedRegions {
+    int n;
+    int first[5];
+    int col_begin[4], strips[4], row_begin[4], row_end[4], rows_per_seg[4];
+};
+
+template <typename T, int LPP, int FW>
+__global__ __launch_bounds__(64 * FW) void fused_regions_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
+                                                                const uint8_t *__restrict__ cost, T lambda,
+                                                                FusedRegions reg)
+{
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < reg.n && b >= reg.first[k + 1]) ++k;
+    const int local = b - reg.first[k];
+    fused_iteration_block<T, LPP, FW>(g, phi, np, cost, lambda, reg.row_begin[k], reg.row_end[k], reg.rows_per_seg[k],
+                                      reg.col_begin[k], local % reg.strips[k], local / reg.strips[k]);
 }
 
 // ---- energy and residual ----------------------------------------------------------

@@ -114,6 +114,20 @@ def lib():
     return _LIB
 
 
+def hip_runtime():
+    """The HIP runtime the library itself is bound to, for callers that move device memory with
+    hipMemcpy and the like.  A process can hold a second copy of libamdhip64 (torch bundles one):
+    pointers and streams of one copy mean nothing to the other, so do not dlopen the runtime by
+    name.  Symbols are looked up through the library's own dependencies."""
+    L = lib()
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.hipFree.argtypes = [C.c_void_p]
+    L.hipStreamSynchronize.argtypes = [C.c_void_p]
+    return L
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 

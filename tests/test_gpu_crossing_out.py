@@ -125,7 +125,7 @@ def test_bands_on_one_gpu_match_whole_image(iters, eps):
     """Three band handles in one process, phi and mask halo rows copied device to device
     through ds_halo / ds_co_halo: every band ends with its rows of the whole image's result."""
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
+    hip = diffstereo.hip_runtime()
     H, W, D = 11, 18, 12
     left, right = random_pair(H, W, seed=5)
     whole = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f64")

@@ -53,12 +53,25 @@ def test_pairs_of_iterations_equal_single_iterations(monkeypatch, H, W, D):
 
 
 def test_handles_without_an_interior_fall_back():
-    for H, W, D, dtype in ((20, 290, 256, "f32"), (11, 400, 256, "f32"), (20, 400, 200, "f32"), (20, 400, 256, "f64")):
+    for H, W, D, dtype in ((20, 52, 40, "f32"), (11, 400, 256, "f32"), (20, 400, 200, "f32"), (20, 400, 256, "f64")):
         left, right = random_pair(H, W, seed=3)
         g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
         assert not g.fused2_info()["available"], (H, W, D, dtype)
         g.iterate(5)
         f = FastOracle(left, right, D, 1.2, dtype=dtype)
+        f.iterate(5)
+        assert np.array_equal(g.get_phi(), f.potentials)
+        g.close()
+    # an image with no column where every label exists: the two-iteration kernel takes it all the
+    # same (labels d > j are masked in its strips left of column D)
+    for H, W, D in ((20, 290, 256), (24, 200, 128), (20, 300, 128)):
+        left, right = random_pair(H, W, seed=5)
+        g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+        info = g.fused2_info()
+        assert info["available"] and info["cols"][0] < D, (H, W, D, info)
+        g.iterate(5)
+        assert g.fused2_info()["steps"] == 2
+        f = FastOracle(left, right, D, 1.2, dtype="f32")
         f.iterate(5)
         assert np.array_equal(g.get_phi(), f.potentials)
         g.close()

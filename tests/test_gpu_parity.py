@@ -116,7 +116,7 @@ def test_bands_bit_identical_to_whole_image(dtype):
     """Three bands on one GPU with the halo rows moved through ds_halo's device
     pointers must reproduce the unpartitioned result bit for bit."""
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
+    hip = diffstereo.hip_runtime()
     H, W, D = 11, 37, 20
     left, right = random_pair(H, W, seed=77)
     phi0 = random_phi(H, W, D, dtype, seed=3)
@@ -213,7 +213,7 @@ def test_full_size_4k_256_properties(monkeypatch):
     the whole image (checksum of checksums, energy, labels), the top rows bit-exact against
     the O(D) oracle on a crop, crossing-out idempotent."""
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
+    hip = diffstereo.hip_runtime()
     H, W, D = 2160, 3840, 256
     monkeypatch.setenv("DS_PLACEMENT_TRIES", "2")
     left, right, _ = synth.synthetic_pair(H, W, D)

@@ -17,18 +17,16 @@ pytestmark = pytest.mark.gpu
 load_package()
 from stereo_vision_amd import diffstereo  # noqa: E402
 
-hip = C.CDLL("libamdhip64.so")
-hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-hip.hipFree.argtypes = [C.c_void_p]
-hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
 D2H = 2
+hip = None
 
 
 class DeviceDoubles:
     """Two doubles of device memory owned by the test (the caller's output buffer)."""
 
     def __init__(self):
+        global hip
+        hip = diffstereo.hip_runtime()  # the runtime the library is bound to, not a second copy
         self.ptr = C.c_void_p()
         assert hip.hipMalloc(C.byref(self.ptr), 16) == 0
         assert hip.hipMemset(self.ptr, 0xFF, 16) == 0
