@@ -18,6 +18,8 @@
 // (ev_side).  Both streams have the default priority.  RCCL's kernel is queued on the boundary
 // stream itself, so no third stream and no cycle of waits exists: main -> side -> main.
 #pragma once
+#include <chrono>
+#include <cstdio>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -486,6 +488,7 @@ int ds_band_iterate(ds_handle *h, int n_iters)
     int fb = 0, fe = 0;
     if (h->fused_waves) fused_safe_rows(h, &fb, &fe);
     const bool fused = n_iters > 0 && fe - fb >= 4 && g.Hb >= 8;
+    const auto host_begin = std::chrono::steady_clock::now();
     if (fused) {
         // two iterations per step while more than two remain (the last one runs alone: see ds_iterate)
         int left = n_iters;
@@ -501,8 +504,15 @@ int ds_band_iterate(ds_handle *h, int n_iters)
         for (int it = 0; it < n_iters && rc == DS_OK; ++it)
             for (int colour = 0; colour < 2 && rc == DS_OK; ++colour) rc = band_half_sweep(h, colour);
     }
+    const auto host_queued = std::chrono::steady_clock::now();
     // also after a failure: nothing of this call may still be running when it returns
     const hipError_t e1 = hipStreamSynchronize(h->side_stream), e2 = hipStreamSynchronize(h->stream);
+    if (std::getenv("DS_BAND_HOST_TIME")) {  // diagnostic: is the host that queues the work the limit?
+        const auto done = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "ds_band_iterate(%d): %.3f ms queueing, %.3f ms until the device was done\n", n_iters,
+                     std::chrono::duration<double, std::milli>(host_queued - host_begin).count(),
+                     std::chrono::duration<double, std::milli>(done - host_begin).count());
+    }
     if (rc != DS_OK) return rc;
     if (e1 != hipSuccess) return fail_hip(h, "hipStreamSynchronize(boundary stream)", e1);
     if (e2 != hipSuccess) return fail_hip(h, "hipStreamSynchronize", e2);
