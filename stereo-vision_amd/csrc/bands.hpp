@@ -266,29 +266,29 @@ int band_fused2_step(ds_handle *h)
         const int n = colour == 0 ? 2 : 1;  // the first colour's two rows feed the second colour's one
         return launch_sweep(h, colour, rb, up ? rb + n : rb, &geo, down ? re - n : re, re);
     };
-    // Three queues beside each other.  Boundary stream: only what the four exchanges wait for or
-    // follow from.  Frame stream: the frame's launches, which read X and Y inside the band only;
-    // the two that make Y's rows next to the boundary rows come first, the boundary stream waits
-    // for them before it reads Y there.  Handle's stream: the interior.  Every launch of the step
-    // writes its own part of Y or Z; the step ends when all three have.
+    // Three queues beside each other.  Boundary stream: the four half-sweeps of the band's first /
+    // last rows, each followed by its exchange -- nothing else, every launch on it waits for compute
+    // units the interior kernel holds.  Frame stream: the frame's launches, which read X and Y
+    // inside the band only.  Handle's stream: the interior.  Two events tie the first two together:
+    // the second iteration's boundary rows read Y's rows next to them (frame stream, ev_rows), and
+    // the frame's rows of the second iteration read Y's boundary and halo rows (boundary stream,
+    // after the second exchange: ev_halo).  Every launch of the step writes its own part of Y or
+    // Z; the step ends when all three queues have.
     int rc = need_frame_stream(h);
     if (rc == DS_OK) rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
     if (rc == DS_OK) HIPCHK(h, hipStreamWaitEvent(h->frame_stream, h->ev_main, 0));
     if (rc != DS_OK) return rc;
+    const FrameRegion rows1[2] = {{0, all, top0, p.rT + 2}, {0, all, p.rB - 2, bot1}};
+    const FrameRegion cols1[2] = {{0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2}, {right0, right_strips, p.rT + 2, p.rB - 2}};
+    const FrameRegion cols2[2] = {{0, p.cL / p.strip1, p.rT, p.rB},
+                                  {p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB}};
+    const FrameRegion rows2[2] = {{0, all, top0, p.rT}, {0, all, p.rB, bot1}};
+    // iteration n + 1 on the widened frame, X -> Y: rows, then columns
     rc = on_stream(h, h->frame_stream, [&]() -> int {
-        // iteration n + 1 on the widened frame: X -> Y
-        const FrameRegion rows1[2] = {{0, all, top0, p.rT + 2}, {0, all, p.rB - 2, bot1}};
-        const FrameRegion cols1[2] = {{0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2},
-                                      {right0, right_strips, p.rT + 2, p.rB - 2}};
-        // iteration n + 2 on the frame's columns: Y -> Z (rows rT - 2 .. rB + 2 of Y: the launches above)
-        const FrameRegion cols2[2] = {{0, p.cL / p.strip1, p.rT, p.rB},
-                                      {p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB}};
         int r = launch_fused_regions(h, X, Y, rows1, 2, 1);
         if (r != DS_OK) return r;
         HIPCHK(h, hipEventRecord(h->ev_rows, h->frame_stream));
-        r = launch_fused_regions(h, X, Y, cols1, 2, 1);
-        if (r == DS_OK) r = launch_fused_regions(h, Y, Z, cols2, 2, 1);
-        return r;
+        return launch_fused_regions(h, X, Y, cols1, 2, 1);
     });
     if (rc != DS_OK) return rc;
     rc = on_side_stream(h, [&]() -> int {
@@ -297,18 +297,26 @@ int band_fused2_step(ds_handle *h)
         if (r == DS_OK) r = exchange_planes(h, g.plane_off[0], side);
         if (r == DS_OK) r = sweep_boundary(1, Y);
         if (r == DS_OK) r = exchange_planes(h, Y, side);
-        // iteration n + 2: the first colour's boundary rows read Y's rows below / above them
         if (r != DS_OK) return r;
+        HIPCHK(h, hipEventRecord(h->ev_halo, side));
+        // iteration n + 2: the first colour's boundary rows read Y's rows below / above them
         HIPCHK(h, hipStreamWaitEvent(side, h->ev_rows, 0));
         r = sweep_boundary(0, Y);
         if (r == DS_OK) r = exchange_planes(h, g.plane_off[0], side);
         if (r == DS_OK) r = sweep_boundary(1, Z);
         if (r == DS_OK) r = exchange_planes(h, Z, side);
-        // the frame's rows, Y -> Z: they read Y's boundary and halo rows (second exchange)
-        const FrameRegion rows2[2] = {{0, all, top0, p.rT}, {0, all, p.rB, bot1}};
-        if (r == DS_OK) r = launch_fused_regions(h, Y, Z, rows2, 2, 1);
         return r;
     });
+    if (rc != DS_OK) return rc;
+    // iteration n + 2 on the frame, Y -> Z: columns (rows rT - 2 .. rB + 2 of Y: the launches
+    // above), then rows (Y's boundary and halo rows: the second exchange)
+    rc = on_stream(h, h->frame_stream, [&]() -> int {
+        int r = launch_fused_regions(h, Y, Z, cols2, 2, 1);
+        if (r != DS_OK) return r;
+        HIPCHK(h, hipStreamWaitEvent(h->frame_stream, h->ev_halo, 0));
+        return launch_fused_regions(h, Y, Z, rows2, 2, 1);
+    });
+    if (rc != DS_OK) return rc;
     if (rc == DS_OK) rc = launch_fused2_interior(h);
     if (rc == DS_OK) rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
     if (rc == DS_OK) rc = order_streams(h, h->frame_stream, h->ev_frame, h->stream);

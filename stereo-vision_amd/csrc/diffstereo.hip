@@ -11,6 +11,8 @@
 #include <limits>
 #include <mutex>
 #include <new>
+#include <algorithm>
+#include <functional>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -69,6 +71,11 @@ struct ds_handle {
     struct Fused2Plan {
         bool ok = false;
         int cL = 0, cR = 0, strips = 0, rT = 0, rB = 0, strip1 = 0, waves = 16;
+        // row segments of the interior launch, chosen at its first launch (launch_fused2_interior)
+        bool segmented = false;
+        int segs = 0;
+        int seg_begin[17] = {};  // unequal segments when seg_count > 0
+        int seg_count = 0;
     } plan2;
     void *phi_y = nullptr;
     long long y_off[4] = {0, 0, 0, 0};
@@ -108,7 +115,7 @@ struct ds_handle {
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     // a band's two-iteration step: the frame's launches that no exchange waits for
     hipStream_t frame_stream = nullptr;
-    hipEvent_t ev_frame = nullptr, ev_rows = nullptr;
+    hipEvent_t ev_frame = nullptr, ev_rows = nullptr, ev_halo = nullptr;
     int *d_flag = nullptr;  // one int on the device for the bands' agreement on not_empty
 
     bool prof = false;
@@ -243,6 +250,7 @@ void release(ds_handle *h)
     }
     if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
     if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
+    if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     (void)hipFree(h->d_flag);
@@ -481,6 +489,7 @@ int need_frame_stream(ds_handle *h)
     if (!h->frame_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->frame_stream, hipStreamNonBlocking));
     if (!h->ev_frame) HIPCHK(h, hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
     if (!h->ev_rows) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming));
+    if (!h->ev_halo) HIPCHK(h, hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
     return DS_OK;
 }
 
@@ -569,33 +578,73 @@ int fused2_step(ds_handle *h)
 int launch_fused2_interior(ds_handle *h)
 {
     ds::Geometry &g = h->g;
-    const ds_handle::Fused2Plan &p = h->plan2;
+    ds_handle::Fused2Plan &p = h->plan2;
     const long long *Z = h->alt_off;
     const int rows = p.rB - p.rT;
     // Row segments: about 96 rows each (a segment recomputes five rows of the first stages).  One
-    // block fills a CU (161 registers x 12 wavefronts), so the grid runs in rounds of cu_count
-    // blocks; when that leaves only a few rounds (a band: 264 rows of 4K x 256 have 198 strips, 3
-    // segments are 594 blocks = 3 rounds of 93 rows, 5 segments 990 blocks = 4 rounds of 58:
-    // 0.69 against 0.64 ms per iteration) take the number of segments that minimises
-    // rounds x (rows per segment + 5) among those that leave no CU without a block.
+    // block fills a CU (157 registers x 12 wavefronts), so the grid runs in rounds of cu_count
+    // blocks, and when that leaves only a few rounds (a band, a small image) equal segments waste
+    // much of the last one: 264 rows x 211 strips in 6 segments of 44 rows are 4.95 rounds of 49
+    // row steps = 245, against 230 if the work could be cut freely.  Then the segments get unequal
+    // lengths, longest first (blocks are dispatched segment by segment, so this is longest-
+    // processing-time-first list scheduling): k segments with lengths falling linearly to a
+    // fraction f of the first; the (k, f) with the smallest simulated makespan wins (135 + 88 + 41
+    // rows: 233).  Blocks that end at different times also hand compute units to the boundary
+    // stream's small launches more often than once per round.
     int segs = (rows + 95) / 96;
-    if ((long long)p.strips * segs < 4ll * h->cu_count) {
+    ds::RowSegments table{};
+    if (p.segmented) {
+        segs = p.segs;
+        table.n = p.seg_count;
+        for (int i = 0; i <= p.seg_count; ++i) table.begin[i] = p.seg_begin[i];
+    } else if ((long long)p.strips * segs < 4ll * h->cu_count && !std::getenv("DS_FUSED2_ROWS")) {
         long long best = -1;
-        for (int k = 1; k <= (rows + 15) / 16; ++k) {
-            const int per = (rows + k - 1) / k;
-            const long long blocks = (long long)p.strips * ((rows + per - 1) / per);
-            if (blocks < h->cu_count && k < (rows + 15) / 16) continue;
-            const long long cost = ((blocks + h->cu_count - 1) / h->cu_count) * (per + 5);
-            if (best < 0 || cost < best) {
-                best = cost;
-                segs = k;
+        std::vector<long long> cu((size_t)h->cu_count);
+        for (int k = 1; k <= 16 && k * 8 <= rows; ++k) {
+            for (int f10 = 10; f10 >= 1; --f10) {
+                if (k == 1 && f10 < 10) break;
+                // lengths proportional to 1 - (1 - f) i / (k - 1)
+                int len[16], sum = 0;
+                double total = 0.;
+                for (int i = 0; i < k; ++i) total += 1. - (1. - f10 / 10.) * (k > 1 ? (double)i / (k - 1) : 0.);
+                bool usable = true;
+                for (int i = 0; i < k; ++i) {
+                    const double w = 1. - (1. - f10 / 10.) * (k > 1 ? (double)i / (k - 1) : 0.);
+                    len[i] = (int)(rows * w / total + 0.5);
+                    sum += len[i];
+                }
+                len[0] += rows - sum;
+                for (int i = 0; i < k; ++i) usable = usable && len[i] >= 8;
+                if (!usable) continue;
+                // list scheduling in dispatch order, a min-heap over the compute units
+                std::fill(cu.begin(), cu.end(), 0ll);
+                for (int i = 0; i < k; ++i)
+                    for (int sidx = 0; sidx < p.strips; ++sidx) {
+                        std::pop_heap(cu.begin(), cu.end(), std::greater<long long>());
+                        cu.back() += len[i] + 5;
+                        std::push_heap(cu.begin(), cu.end(), std::greater<long long>());
+                    }
+                const long long span = *std::max_element(cu.begin(), cu.end());
+                if (best < 0 || span < best) {
+                    best = span;
+                    table.n = k;
+                    table.begin[0] = p.rT;
+                    for (int i = 0; i < k; ++i) table.begin[i + 1] = table.begin[i] + len[i];
+                }
             }
         }
+        if (table.n > 0) segs = table.n;
+    }
+    if (!p.segmented) {  // the search above costs milliseconds: once per handle
+        p.segmented = true;
+        p.segs = segs;
+        p.seg_count = table.n;
+        for (int i = 0; i <= table.n; ++i) p.seg_begin[i] = table.begin[i];
     }
     if (const char *e = std::getenv("DS_FUSED2_ROWS"))  // tuning knob: rows per segment
         if (std::atoi(e) > 0) segs = (rows + std::atoi(e) - 1) / std::atoi(e);
-    const int rows_per_seg = (rows + segs - 1) / segs;
-    segs = (rows + rows_per_seg - 1) / rows_per_seg;
+    int rows_per_seg = (rows + segs - 1) / segs;
+    if (table.n == 0) segs = (rows + rows_per_seg - 1) / rows_per_seg;
     const bool timed = h->prof && h->prof_n < h->prof_cap;
     if (timed) {
         HIPCHK(h, hipEventRecord(h->events[2 * h->prof_n], h->stream));
@@ -609,7 +658,7 @@ int launch_fused2_interior(ds_handle *h)
     const float lambda = (float)h->lambda;
     auto go = [&](auto lppc, auto wavesc) {
         hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, decltype(lppc)::value, decltype(wavesc)::value>), grid, block,
-                           0, h->stream, in, base, base, np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg);
+                           0, h->stream, in, base, base, np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg, table);
     };
     auto with_waves = [&](auto lppc) {
         if (p.waves == 12) go(lppc, std::integral_constant<int, 12>{});

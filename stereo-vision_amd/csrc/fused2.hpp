@@ -129,12 +129,19 @@ template <typename T, int NP, int DL> struct Fused2Lds {
     T ring3[2][NP][DL];  // C: red -> the neighbouring slot's black (iteration n+2)
 };
 
+// Row segments of unequal length (blockIdx.y -> rows [begin[y], begin[y + 1])), for grids of only a
+// few rounds of blocks: n = 0 means equal segments of rows_per_seg rows.
+struct RowSegments {
+    int n;
+    int begin[17];
+};
+
 template <typename T, int LPP, int FW>
 __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, const T *__restrict__ phi,
                                                                    T *__restrict__ phi_out, FusedPlanes np,
                                                                    const uint8_t *__restrict__ cost, T lambda,
                                                                    int col_begin, int row_begin, int row_end,
-                                                                   int rows_per_seg)
+                                                                   int rows_per_seg, RowSegments segments)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP, NP = FW * PPW, DL = 4 * LPP, FC2 = 2 * (NP - 3);
@@ -152,8 +159,12 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
     const int c0 = col_begin - 2 + (int)blockIdx.x * FC2;
     const int a = c0 - 1 + 2 * kp;  // first column of the slot's pair (odd)
-    const int r0 = row_begin + (int)blockIdx.y * rows_per_seg;
-    const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
+    int r0 = row_begin + (int)blockIdx.y * rows_per_seg;
+    int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
+    if (segments.n > 0) {
+        r0 = segments.begin[blockIdx.y];
+        r1 = segments.begin[blockIdx.y + 1];
+    }
     const uint8_t *cost_red = cost, *cost_black = cost + g.cost_colour_stride;
     const int kl = kp > 0 ? kp - 1 : 0, kr = kp < NP - 1 ? kp + 1 : NP - 1;  // neighbouring slots (clamped: the
                                                                               // strip's outermost slots are not kept)
