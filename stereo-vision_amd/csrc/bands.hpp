@@ -256,7 +256,6 @@ int band_fused2_step(ds_handle *h)
     const bool up = h->up >= 0, down = h->down >= 0;
     const long long *X = g.plane_off[1], *Y = h->y_off, *Z = h->alt_off;
     const int all = (g.W + p.strip1 - 1) / p.strip1;
-    const int right0 = p.cR - p.strip1, right_strips = (g.W - right0 + p.strip1 - 1) / p.strip1;
     // rows the one-iteration kernel takes at the top / bottom of the band (a band's own first /
     // last row only where the image ends there)
     const int top0 = up ? rb + 1 : rb, bot1 = down ? re - 1 : re;
@@ -279,9 +278,8 @@ int band_fused2_step(ds_handle *h)
     if (rc == DS_OK) HIPCHK(h, hipStreamWaitEvent(h->frame_stream, h->ev_main, 0));
     if (rc != DS_OK) return rc;
     const FrameRegion rows1[2] = {{0, all, top0, p.rT + 2}, {0, all, p.rB - 2, bot1}};
-    const FrameRegion cols1[2] = {{0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2}, {right0, right_strips, p.rT + 2, p.rB - 2}};
-    const FrameRegion cols2[2] = {{0, p.cL / p.strip1, p.rT, p.rB},
-                                  {p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB}};
+    const FrameRegion cols1[2] = {{0, p.left1, p.rT + 2, p.rB - 2}, {p.right1_begin, p.right1, p.rT + 2, p.rB - 2}};
+    const FrameRegion cols2[2] = {{0, p.left2, p.rT, p.rB, p.cL}, {p.cR, p.right2, p.rT, p.rB}};
     const FrameRegion rows2[2] = {{0, all, top0, p.rT}, {0, all, p.rB, bot1}};
     // iteration n + 1 on the widened frame, X -> Y: rows, then columns
     rc = on_stream(h, h->frame_stream, [&]() -> int {

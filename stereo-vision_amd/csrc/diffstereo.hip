@@ -71,6 +71,9 @@ struct ds_handle {
     struct Fused2Plan {
         bool ok = false;
         int cL = 0, cR = 0, strips = 0, rT = 0, rB = 0, strip1 = 0, waves = 16;
+        // the frame's column regions, in strips of the one-iteration kernel: first iteration
+        // (widened by two columns towards the interior) and second
+        int left1 = 0, left2 = 0, right1_begin = 0, right1 = 0, right2 = 0;
         // row segments of the interior launch, chosen at its first launch (launch_fused2_interior)
         bool segmented = false;
         int segs = 0;
@@ -378,6 +381,7 @@ int launch_fused_region(ds_handle *h, const long long in_off[4], const long long
 // Several regions of the same planes in one launch (empty ones are left out).
 struct FrameRegion {
     int col_begin, strips, row_begin, row_end;
+    int col_end = 0x7fffffff;  // columns from here on are another launch's
 };
 
 int launch_fused_regions(ds_handle *h, const long long in_off[4], const long long out_off[4], const FrameRegion *regions,
@@ -393,6 +397,7 @@ int launch_fused_regions(ds_handle *h, const long long in_off[4], const long lon
         const int n = reg.n++;
         reg.first[n] = blocks;
         reg.col_begin[n] = r.col_begin;
+        reg.col_end[n] = r.col_end;
         reg.strips[n] = r.strips;
         reg.row_begin[n] = r.row_begin;
         reg.row_end[n] = r.row_end;
@@ -517,13 +522,15 @@ void plan_fused2(ds_handle *h)
     if (const char *w = std::getenv("DS_F2_WAVES")) p.waves = std::atoi(w) == 16 ? 16 : 12;  // tuning knob
     const int FC1 = 2 * (16 * (64 / h->lpp) - 1);                 // the one-iteration kernel's strip
     const int NP = p.waves * (64 / h->lpp), FC2 = 2 * (NP - 3);   // the two-iteration kernel's slots and strip
-    // Left edge: a multiple of the one-iteration strip.  One strip is enough for every pixel the
-    // kernel touches to have a left neighbour (c0 - 2 = cL - 4 >= 0); DS_FUSED2_LEFT=full keeps
-    // the kernel to the columns where every label exists (c0 - 1 = cL - 3 >= D), for checking.
-    p.cL = FC1;
+    // Left edge: two columns short of a multiple of the one-iteration strip, so that the frame's
+    // first iteration, which must reach two columns into the interior, still fits whole strips.
+    // One strip is enough for every pixel the kernel touches to have a left neighbour (c0 - 2 =
+    // cL - 4 >= 0); DS_FUSED2_LEFT=full keeps the kernel to the columns where every label exists
+    // (c0 - 1 = cL - 3 >= D), for checking.
+    p.cL = FC1 - 2;
     if (const char *l = std::getenv("DS_FUSED2_LEFT")) {
-        if (std::strcmp(l, "full") == 0) p.cL = ((g.D + 3 + FC1 - 1) / FC1) * FC1;
-        else if (std::atoi(l) > 0) p.cL = ((std::atoi(l) + FC1 - 1) / FC1) * FC1;  // tuning knob: columns left to the one-iteration kernel
+        if (std::strcmp(l, "full") == 0) p.cL = ((g.D + 3 + FC1 - 1) / FC1) * FC1 - 2;
+        else if (std::atoi(l) > 0) p.cL = ((std::atoi(l) + FC1 - 1) / FC1) * FC1 - 2;  // tuning knob: columns left to the one-iteration kernel
     }
     const long long room = (long long)g.W - 1 - 2 * NP - (p.cL - 2);  // c0 of the last strip + 2 NP < W
     p.strips = room >= 0 ? (int)(room / FC2) + 1 : 0;
@@ -534,6 +541,11 @@ void plan_fused2(ds_handle *h)
     p.rT = g.row0 == 0 ? 4 : g.row0 + 3;
     p.rB = g.row0 + g.Hb == g.H ? g.H - 4 : g.row0 + g.Hb - 3;
     p.strip1 = FC1;
+    p.left1 = (p.cL + 2 + FC1 - 1) / FC1;
+    p.left2 = (p.cL + FC1 - 1) / FC1;  // its last strip is cut off at cL (FrameRegion::col_end)
+    p.right1_begin = p.cR - 2;
+    p.right1 = (g.W - p.right1_begin + FC1 - 1) / FC1;
+    p.right2 = (g.W - p.cR + FC1 - 1) / FC1;
     p.ok = p.strips >= 1 && p.rB - p.rT >= 8;
 }
 
@@ -548,18 +560,17 @@ int fused2_step(ds_handle *h)
     int rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
     if (rc != DS_OK) return rc;
     rc = on_side_stream(h, [&]() -> int {
-        const int right0 = p.cR - p.strip1;
         // first iteration on the widened frame, X -> Y; second iteration on the frame, Y -> Z: one
         // launch each (a stream of eight small dependent launches beside a kernel that fills the
         // device gets compute units only as that kernel's blocks end, launch after launch)
         const FrameRegion first[4] = {{0, all, 0, p.rT + 2},
                                       {0, all, p.rB - 2, g.H},
-                                      {0, p.cL / p.strip1 + 1, p.rT + 2, p.rB - 2},
-                                      {right0, (g.W - right0 + p.strip1 - 1) / p.strip1, p.rT + 2, p.rB - 2}};
+                                      {0, p.left1, p.rT + 2, p.rB - 2},
+                                      {p.right1_begin, p.right1, p.rT + 2, p.rB - 2}};
         const FrameRegion second[4] = {{0, all, 0, p.rT},
                                        {0, all, p.rB, g.H},
-                                       {0, p.cL / p.strip1, p.rT, p.rB},
-                                       {p.cR, (g.W - p.cR + p.strip1 - 1) / p.strip1, p.rT, p.rB}};
+                                       {0, p.left2, p.rT, p.rB, p.cL},
+                                       {p.cR, p.right2, p.rT, p.rB}};
         int r = launch_fused_regions(h, X, Y, first, 4, 1);
         if (r == DS_OK) r = launch_fused_regions(h, Y, Z, second, 4, 1);
         return r;

@@ -644,7 +644,8 @@ template <typename T, int NP, int DL> struct FusedLds {
 template <typename T, int LPP, int FW>
 __device__ __forceinline__ void fused_iteration_block(const Geometry &g, T *__restrict__ phi, const FusedPlanes &np,
                                                       const uint8_t *__restrict__ cost, T lambda, int row_begin,
-                                                      int row_end, int rows_per_seg, int col_begin, int strip, int seg)
+                                                      int row_end, int rows_per_seg, int col_begin, int col_end,
+                                                      int strip, int seg)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP, NP = FW * PPW, NB = NP - 1, FC = 2 * NB, DL = 4 * LPP;
@@ -660,7 +661,8 @@ __device__ __forceinline__ void fused_iteration_block(const Geometry &g, T *__re
     const int a = c0 - 1 + 2 * kp;  // first column of the slot's pair (odd)
     const int r0 = row_begin + seg * rows_per_seg;
     const int r1 = r0 + rows_per_seg < row_end ? r0 + rows_per_seg : row_end;
-    const bool cols_interior = g.D == DL && c0 - 1 >= g.D && c0 + FC + 1 < g.W;
+    // col_end: columns from there on belong to another launch (the last strip may reach beyond)
+    const bool cols_interior = g.D == DL && c0 - 1 >= g.D && c0 + FC + 1 < g.W && c0 + FC <= col_end;
     const uint8_t *cost_red = cost, *cost_black = cost + g.cost_colour_stride;
 
     // what fetch() keeps for produce(): the four neighbour rows and the packed cost word (the
@@ -764,7 +766,7 @@ __device__ __forceinline__ void fused_iteration_block(const Geometry &g, T *__re
             }
         } else {
             Pixel px = locate(g, i, (i + 1) & 1, jc, d0);
-            px.active = px.active && mine && j >= 0;
+            px.active = px.active && mine && j >= 0 && j < col_end;
             const V4<T> none = splat(inf);
             const bool has_across = px.active && (p ? px.has[2] : px.has[0]);
             const bool has_own = px.active && (p ? px.has[0] : px.has[2]);
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
                                                                   int col_begin)
 {
     fused_iteration_block<T, LPP, FW>(g, phi, np, cost, lambda, row_begin, row_end, rows_per_seg, col_begin,
-                                      (int)blockIdx.x, (int)blockIdx.y);
+                                      0x7fffffff, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // Up to four rectangular regions in one launch (the frame around a two-iteration step's interior:
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T 
 struct FusedRegions {
     int n;
     int first[5];
-    int col_begin[4], strips[4], row_begin[4], row_end[4], rows_per_seg[4];
+    int col_begin[4], col_end[4], strips[4], row_begin[4], row_end[4], rows_per_seg[4];
 };
 
 template <typename T, int LPP, int FW>
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(64 * FW) void fused_regions_kernel(Geometry g, T *_
     while (k + 1 < reg.n && b >= reg.first[k + 1]) ++k;
     const int local = b - reg.first[k];
     fused_iteration_block<T, LPP, FW>(g, phi, np, cost, lambda, reg.row_begin[k], reg.row_end[k], reg.rows_per_seg[k],
-                                      reg.col_begin[k], local % reg.strips[k], local / reg.strips[k]);
+                                      reg.col_begin[k], reg.col_end[k], local % reg.strips[k], local / reg.strips[k]);
 }
 
 // ---- energy and residual ----------------------------------------------------------
