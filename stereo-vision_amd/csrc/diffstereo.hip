@@ -108,6 +108,9 @@ struct ds_handle {
     size_t eps_count = 0;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // set around the last launch(es) of ds_iterate: the fused kernels then store the first colour
+    // too, and no half-sweep has to bring it up to date afterwards
+    bool store_first = false;
 
     // row bands over several ranks (bands.hpp): how halo rows travel, who the neighbours are,
     // and the stream / events that run a band's boundary rows beside its interior kernel
@@ -358,11 +361,11 @@ int launch_fused_region(ds_handle *h, const long long in_off[4], const long long
             if (h->probing)
                 hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, true>), grid, block, 0, h->stream, geo,
                                    static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end,
-                                   rows_per_seg, col_begin);
+                                   rows_per_seg, col_begin, h->store_first ? 1 : 0);
             else
                 hipLaunchKernelGGL((ds::fused_iteration_kernel<T, L, FW, false>), grid, block, 0, h->stream, geo,
                                    static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, row_begin, row_end,
-                                   rows_per_seg, col_begin);
+                                   rows_per_seg, col_begin, h->store_first ? 1 : 0);
         };
         if (fw == 16) go(std::integral_constant<int, 16>{});
         else if (fw == 8) go(std::integral_constant<int, 8>{});
@@ -423,7 +426,7 @@ int launch_fused_regions(ds_handle *h, const long long in_off[4], const long lon
         auto go = [&](auto fwc) {
             constexpr int FW = decltype(fwc)::value;
             hipLaunchKernelGGL((ds::fused_regions_kernel<T, L, FW>), grid, block, 0, h->stream, geo,
-                               static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, reg);
+                               static_cast<T *>(h->phi), np, h->cost_px, (T)h->lambda, reg, h->store_first ? 1 : 0);
         };
         if (fw == 16) go(std::integral_constant<int, 16>{});
         else if (fw == 8) go(std::integral_constant<int, 8>{});
@@ -456,7 +459,7 @@ int launch_fused(ds_handle *h, int row_begin, int row_end)
                                  row_end, 1);
     if (rc != DS_OK) return rc;
     for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
-    h->fused_pending = true;
+    h->fused_pending = !h->store_first;
     return DS_OK;
 }
 
@@ -571,7 +574,12 @@ int fused2_step(ds_handle *h)
                                        {0, all, p.rB, g.H},
                                        {0, p.left2, p.rT, p.rB, p.cL},
                                        {p.cR, p.right2, p.rT, p.rB}};
+        // the first pass makes iteration n+1 (also on pixels the interior kernel finishes): it never
+        // stores the first colour, the second pass does when this is the call's last step
+        const bool last = h->store_first;
+        h->store_first = false;
         int r = launch_fused_regions(h, X, Y, first, 4, 1);
+        h->store_first = last;
         if (r == DS_OK) r = launch_fused_regions(h, Y, Z, second, 4, 1);
         return r;
     });
@@ -580,7 +588,7 @@ int fused2_step(ds_handle *h)
     if (rc == DS_OK) rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
     if (rc != DS_OK) return rc;
     for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
-    h->fused_pending = true;
+    h->fused_pending = !h->store_first;
     return DS_OK;
 }
 
@@ -669,7 +677,8 @@ int launch_fused2_interior(ds_handle *h)
     const float lambda = (float)h->lambda;
     auto go = [&](auto lppc, auto wavesc) {
         hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, decltype(lppc)::value, decltype(wavesc)::value>), grid, block,
-                           0, h->stream, in, base, base, np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg, table);
+                           0, h->stream, in, base, base, np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg, table,
+                           h->store_first ? 1 : 0);
     };
     auto with_waves = [&](auto lppc) {
         if (p.waves == 12) go(lppc, std::integral_constant<int, 12>{});
@@ -1259,25 +1268,34 @@ int ds_iterate(ds_handle *h, int n_iters)
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
     if (h->fused_waves && n_iters > 0) {
-        // n whole iterations that move only the second colour's planes, then the first
-        // colour's planes brought up to date: the same bits as 2n half-sweeps
-        // Two iterations per launch while more than two remain: the last one always runs alone,
-        // because bringing the first colour up to date needs the second colour's planes of the
-        // iteration before the last, and a two-iteration step never stores its middle state.
+        // n whole iterations that move only the second colour's planes; the call's last launch
+        // also stores the first colour (the kernels compute it on the way): the same bits as 2n
+        // half-sweeps.  Two iterations per launch while two or more remain.
+        // DS_STORE_FIRST=off, for checking: the last iteration runs alone and a half-sweep brings the
+        // first colour up to date from the second colour's planes of the iteration before
+        const char *sf = std::getenv("DS_STORE_FIRST");
+        const bool fold = !(sf && std::strcmp(sf, "off") == 0);
+        const int keep = fold ? 2 : 3;
         int left = n_iters;
-        if (left >= 3 && prepare_fused2(h)) {
-            while (left >= 3) {
-                rc = fused2_step(h);
-                if (rc != DS_OK) return rc;
-                ++h->fused2_steps;
-                left -= 2;
-            }
+        const bool by_two = left >= keep && prepare_fused2(h);
+        struct Restore {
+            ds_handle *h;
+            ~Restore() { h->store_first = false; }
+        } restore{h};
+        while (by_two && left >= keep) {
+            h->store_first = fold && left == 2;
+            rc = fused2_step(h);
+            if (rc != DS_OK) return rc;
+            ++h->fused2_steps;
+            left -= 2;
         }
-        for (int it = 0; it < left; ++it) {
+        for (; left > 0; --left) {
+            h->store_first = fold && left == 1;
             rc = launch_fused(h, 0, h->g.H);
             if (rc != DS_OK) return rc;
         }
-        rc = materialise_first_colour(h, 0, h->g.H);
+        h->store_first = false;
+        rc = materialise_first_colour(h, 0, h->g.H);  // nothing left to do unless DS_STORE_FIRST=off
         if (rc != DS_OK) return rc;
     } else {
         for (int it = 0; it < n_iters; ++it)

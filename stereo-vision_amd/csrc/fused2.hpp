@@ -141,7 +141,8 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
                                                                    T *__restrict__ phi_out, FusedPlanes np,
                                                                    const uint8_t *__restrict__ cost, T lambda,
                                                                    int col_begin, int row_begin, int row_end,
-                                                                   int rows_per_seg, RowSegments segments)
+                                                                   int rows_per_seg, RowSegments segments,
+                                                                   int store_first)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP, NP = FW * PPW, DL = 4 * LPP, FC2 = 2 * (NP - 3);
@@ -260,6 +261,14 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         psi[2] = P ? b_side_cur : across;
         psi[3] = b_up_next;
         update(psi, cost_word(cost_red, r, j), j, out);
+        // the last launch of a call also stores the first colour of iteration n+2: the block's own
+        // rows, the strip's own columns (odd row: the red pixels of slots 2 .. NP - 2, even row:
+        // 1 .. NP - 3); nothing reads those planes while iterations run
+        if (store_first && r >= r0 && r < r1 && (P ? (kp >= 2 && kp <= NP - 2) : (kp >= 1 && kp <= NP - 3))) {
+            const long long own = (long long)(r - g.row0 + 1) * g.row_stride + (long long)(j >> 1) * g.Dpad + d0;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) st4_nt(phi_out + g.plane_off[0][n] + own, out[n]);
+        }
         store4(&lds.ring3[P][kp][d0], P ? out[0] : out[2]);
         c_side_next = P ? out[2] : out[0];
         c_up_next = out[1];

@@ -645,7 +645,7 @@ template <typename T, int LPP, int FW>
 __device__ __forceinline__ void fused_iteration_block(const Geometry &g, T *__restrict__ phi, const FusedPlanes &np,
                                                       const uint8_t *__restrict__ cost, T lambda, int row_begin,
                                                       int row_end, int rows_per_seg, int col_begin, int col_end,
-                                                      int strip, int seg)
+                                                      int strip, int seg, int store_first)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP, NP = FW * PPW, NB = NP - 1, FC = 2 * NB, DL = 4 * LPP;
@@ -726,6 +726,27 @@ __device__ __forceinline__ void fused_iteration_block(const Geometry &g, T *__re
                 const bool valid = px.active && d0 + c <= K;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) out[n].v[c] = (valid && px.has[n]) ? avg - M[n].v[c] : inf;
+            }
+        }
+        // The last launch of a call also stores the first colour (nothing reads those planes while
+        // iterations run): the block's own rows, the strip's own columns -- in an odd row the red
+        // pixels of slots 1 .. NP - 1, in an even row those of slots 0 .. NP - 2 -- and, as
+        // sweep_kernel does it, neither a slot towards a neighbour that does not exist nor a vector
+        // without a valid label.
+        if (store_first && r >= r0 && r < r1 && (p ? kp >= 1 : kp <= NB - 1)) {
+            const int j = p ? a : a + 1;
+            const long long own = (long long)(r - g.row0 + 1) * g.row_stride + (long long)(j >> 1) * g.Dpad + d0;
+            if (cols_interior && r >= 1 && r + 1 < g.H) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) st4_nt(phi + g.plane_off[0][n] + own, out[n]);
+            } else {
+                const Pixel px = red_pixel(r);
+                const int K = px.j < g.D - 1 ? px.j : g.D - 1;
+                if (px.active && j < col_end && d0 <= K) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        if (px.has[n]) store4(phi + g.plane_off[0][n] + own, out[n]);
+                }
             }
         }
         // odd row: red at a, its right neighbour is the slot's own black pixel, its left one the
@@ -828,10 +849,10 @@ template <typename T, int LPP, int FW, bool PROBE = false>
 __global__ __launch_bounds__(64 * FW) void fused_iteration_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
                                                                   const uint8_t *__restrict__ cost, T lambda,
                                                                   int row_begin, int row_end, int rows_per_seg,
-                                                                  int col_begin)
+                                                                  int col_begin, int store_first)
 {
     fused_iteration_block<T, LPP, FW>(g, phi, np, cost, lambda, row_begin, row_end, rows_per_seg, col_begin,
-                                      0x7fffffff, (int)blockIdx.x, (int)blockIdx.y);
+                                      0x7fffffff, (int)blockIdx.x, (int)blockIdx.y, store_first);
 }
 
 // Up to four rectangular regions in one launch (the frame around a two-iteration step's interior:
@@ -848,14 +869,15 @@ struct FusedRegions {
 template <typename T, int LPP, int FW>
 __global__ __launch_bounds__(64 * FW) void fused_regions_kernel(Geometry g, T *__restrict__ phi, FusedPlanes np,
                                                                 const uint8_t *__restrict__ cost, T lambda,
-                                                                FusedRegions reg)
+                                                                FusedRegions reg, int store_first)
 {
     const int b = (int)blockIdx.x;
     int k = 0;
     while (k + 1 < reg.n && b >= reg.first[k + 1]) ++k;
     const int local = b - reg.first[k];
     fused_iteration_block<T, LPP, FW>(g, phi, np, cost, lambda, reg.row_begin[k], reg.row_end[k], reg.rows_per_seg[k],
-                                      reg.col_begin[k], reg.col_end[k], local % reg.strips[k], local / reg.strips[k]);
+                                      reg.col_begin[k], reg.col_end[k], local % reg.strips[k], local / reg.strips[k],
+                                      store_first);
 }
 
 // ---- energy and residual ----------------------------------------------------------

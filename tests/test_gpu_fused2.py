@@ -36,11 +36,11 @@ def test_pairs_of_iterations_equal_single_iterations(monkeypatch, H, W, D):
         g.set_phi(phi0)
     f.potentials[...] = phi0
     steps = 0
-    for n in (3, 4, 7, 2, 1, 5):   # 1, 1, 3, 0, 0, 2 two-iteration steps
+    for n in (3, 4, 7, 2, 1, 5):   # 1, 2, 3, 1, 0, 2 two-iteration steps (the call's last launch also stores the first colour)
         g1.iterate(n)
         g2.iterate(n)
         f.iterate(n)
-        steps += (n - 1) // 2
+        steps += n // 2
         phi = g2.get_phi()
         assert np.array_equal(phi, g1.get_phi()), "after a call of %d iterations" % n
         assert np.array_equal(phi, f.potentials), "oracle, after a call of %d iterations" % n
@@ -101,3 +101,35 @@ def test_full_size_4k_256(monkeypatch):
     f = FastOracle(left[:40], right[:40], D, 1.2, dtype="f32")
     f.iterate(9)
     assert np.array_equal(top, f.potentials[:20])
+
+
+@pytest.mark.parametrize("dtype,H,W,D", [("f32", 21, 401, 256), ("f32", 19, 333, 128), ("f32", 17, 390, 64),
+                                          ("f32", 15, 77, 40), ("f64", 18, 140, 100), ("f64", 13, 300, 256),
+                                          ("f32", 9, 35, 24)])
+def test_last_launch_stores_the_first_colour(monkeypatch, dtype, H, W, D):
+    """ds_iterate's last launch writes the first colour's planes itself; with DS_STORE_FIRST=off a
+    half-sweep does it afterwards from the planes of the iteration before.  Every plane of both
+    colours must come out the same, call after call, and equal to the oracle's."""
+    left, right = random_pair(H, W, seed=H * W + D)
+    phi0 = random_phi(H, W, D, dtype, seed=11)
+    a = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    b = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    f = FastOracle(left, right, D, 1.2, dtype=dtype)
+    a.set_phi(phi0)
+    b.set_phi(phi0)
+    f.potentials[...] = phi0
+    for n in (1, 2, 3, 4, 1):
+        a.iterate(n)
+        monkeypatch.setenv("DS_STORE_FIRST", "off")
+        b.iterate(n)
+        monkeypatch.delenv("DS_STORE_FIRST")
+        f.iterate(n)
+        got = a.get_phi()
+        assert np.array_equal(got, b.get_phi()), "after a call of %d iterations" % n
+        assert np.array_equal(got, f.potentials), "oracle, after a call of %d iterations" % n
+        assert a.checksum() == b.checksum() and a.energy() == b.energy()
+    a.sweep(0)   # the handle is in the state half-sweeps expect
+    b.sweep(0)
+    assert np.array_equal(a.get_phi(), b.get_phi())
+    a.close()
+    b.close()

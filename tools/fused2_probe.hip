@@ -616,9 +616,9 @@ int main(int argc, char **argv)
             float ms = 0;
             CK(hipEventRecord(e0));
             hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 64, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
-                               dim3(64 * 16), 0, 0, g, phi, np1, cost, lambda, 0, g.H, rps, 0);
+                               dim3(64 * 16), 0, 0, g, phi, np1, cost, lambda, 0, g.H, rps, 0, 0);
             hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 64, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
-                               dim3(64 * 16), 0, 0, g2, phi, np2, cost, lambda, 0, g.H, rps, 0);
+                               dim3(64 * 16), 0, 0, g2, phi, np2, cost, lambda, 0, g.H, rps, 0, 0);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             CK(hipGetLastError());
@@ -676,9 +676,9 @@ int main(int argc, char **argv)
             float ms = 0;
             CK(hipEventRecord(e0));
             hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 64, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
-                               dim3(64 * 16), 0, 0, g, phi, np1, cost, lambda, 0, g.H, rps, 0);
+                               dim3(64 * 16), 0, 0, g, phi, np1, cost, lambda, 0, g.H, rps, 0, 0);
             hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 64, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
-                               dim3(64 * 16), 0, 0, g2, phi, np2, cost, lambda, 0, g.H, rps, 0);
+                               dim3(64 * 16), 0, 0, g2, phi, np2, cost, lambda, 0, g.H, rps, 0, 0);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             CK(hipGetLastError());

@@ -237,7 +237,7 @@ int main(int argc, char **argv)
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0));
                 hipLaunchKernelGGL((ds::fused_iteration_kernel<float, 64, 16, false>), dim3(strips_all, (g.H + rps - 1) / rps),
-                                   dim3(64 * FW), 0, 0, g, phi, np, cost, lambda, 0, g.H, rps, 0);
+                                   dim3(64 * FW), 0, 0, g, phi, np, cost, lambda, 0, g.H, rps, 0, 0);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 CK(hipGetLastError());
