@@ -282,12 +282,15 @@ int band_fused2_step(ds_handle *h)
     const FrameRegion cols2[2] = {{0, p.left2, p.rT, p.rB, p.cL}, {p.cR, p.right2, p.rT, p.rB}};
     const FrameRegion rows2[2] = {{0, all, top0, p.rT}, {0, all, p.rB, bot1}};
     // iteration n + 1 on the widened frame, X -> Y: rows, then columns
+    const bool last = h->store_first;  // the call's last step: its second pass and the interior store the first colour
+    h->store_first = false;
     rc = on_stream(h, h->frame_stream, [&]() -> int {
         int r = launch_fused_regions(h, X, Y, rows1, 2, 1);
         if (r != DS_OK) return r;
         HIPCHK(h, hipEventRecord(h->ev_rows, h->frame_stream));
         return launch_fused_regions(h, X, Y, cols1, 2, 1);
     });
+    h->store_first = last;
     if (rc != DS_OK) return rc;
     rc = on_side_stream(h, [&]() -> int {
         hipStream_t side = h->side_stream;
@@ -320,7 +323,7 @@ int band_fused2_step(ds_handle *h)
     if (rc == DS_OK) rc = order_streams(h, h->frame_stream, h->ev_frame, h->stream);
     if (rc != DS_OK) return rc;
     for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
-    h->fused_pending = true;
+    h->fused_pending = !h->store_first;
     return DS_OK;
 }
 
@@ -497,14 +500,24 @@ int ds_band_iterate(ds_handle *h, int n_iters)
     const auto host_begin = std::chrono::steady_clock::now();
     if (fused) {
         // two iterations per step while more than two remain (the last one runs alone: see ds_iterate)
+        // as in ds_iterate: the call's last launches also store the first colour (the band's first /
+        // last rows get theirs from the boundary half-sweeps in any case)
+        const char *sf = std::getenv("DS_STORE_FIRST");
+        const bool fold = !(sf && std::strcmp(sf, "off") == 0);
+        const int keep = fold ? 2 : 3;
         int left = n_iters;
-        if (left >= 3 && prepare_fused2(h)) {
-            for (; left >= 3 && rc == DS_OK; left -= 2) {
+        if (left >= keep && prepare_fused2(h)) {
+            for (; left >= keep && rc == DS_OK; left -= 2) {
+                h->store_first = fold && left == 2;
                 rc = band_fused2_step(h);
                 ++h->fused2_steps;
             }
         }
-        for (int it = 0; it < left && rc == DS_OK; ++it) rc = band_fused_iteration(h, fb, fe);
+        for (; left > 0 && rc == DS_OK; --left) {
+            h->store_first = fold && left == 1;
+            rc = band_fused_iteration(h, fb, fe);
+        }
+        h->store_first = false;
         if (rc == DS_OK) rc = materialise_first_colour(h, g.row0, g.row0 + g.Hb);
     } else {
         for (int it = 0; it < n_iters && rc == DS_OK; ++it)
