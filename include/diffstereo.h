@@ -93,8 +93,9 @@ int ds_get_cost(ds_handle *h, uint8_t *out);
  * handle that owns the whole image (bands need the halo exchange between colours:
  * use ds_sweep).  The iterations run in a kernel that keeps the first
  * colour's potentials on chip (they are a function of the second colour's) and moves only
- * the second colour's planes; the first colour's planes are brought up to date before the
- * call returns.  Same bits as the half-sweeps; DS_FUSED=off at ds_create disables it. */
+ * the second colour's planes; the call's last launch stores the first colour's planes as well,
+ * so every other entry point sees the state 2 n_iters half-sweeps leave.  Same bits as the
+ * half-sweeps; DS_FUSED=off at ds_create disables it. */
 int ds_iterate(ds_handle *h, int n_iters);
 
 /* Whole iterations on a row band (no counterpart in the reference, which has one process).  The fused kernel recomputes the first colour's rows i-1..i+1 for every row i
@@ -357,9 +358,9 @@ int ds_profile_split(ds_handle *h, int *n_half_sweeps, double *half_sweep_ms, in
 int ds_profile_kind(ds_handle *h, int kind, int *n_launches, double *ms);
 
 /* Two iterations per launch.  On whole-image f32 handles whose D fills the lanes (D = 64, 128 or
- * 256) ds_iterate runs its iterations in pairs while more than two remain: one kernel computes
- * both iterations on chip for the part of the image where nothing needs masking -- output
- * columns [*col_begin, *col_end), rows [*row_begin, *row_end) -- and the frame around it goes
+ * 256) ds_iterate runs its iterations in pairs: one kernel computes both iterations on chip
+ * for the part of the image where every pixel has four neighbours -- output columns
+ * [*col_begin, *col_end), rows [*row_begin, *row_end) -- and the frame around it goes
  * through the one-iteration kernel twice, beside it on a second stream (a third set of
  * second-colour planes, allocated on first use, holds the frame's middle state; without the
  * memory for it, or with DS_FUSED2=off, every iteration is a launch of its own).  Same bits
