@@ -282,6 +282,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # First use, part of the set-up like ds_create: the two-iteration path allocates its third set of
+    # planes, chooses its row segments and loads its kernels at its first step.  Two iterations
+    # bring that about whatever --warmup says; the W warm-up steps the caller asked for follow.
+    runner.iterate(2)
+    fence()
     runner.iterate(args.warmup)
     fence()
     # launches per step: a band has boundary half-sweeps + the interior kernel; a two-iteration
