@@ -133,3 +133,25 @@ def test_last_launch_stores_the_first_colour(monkeypatch, dtype, H, W, D):
     assert np.array_equal(a.get_phi(), b.get_phi())
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("left_cols", ["full", "90", "200"])
+def test_any_split_between_the_two_kernels_gives_the_same_bits(monkeypatch, left_cols):
+    """DS_FUSED2_LEFT moves the column where the one-iteration kernel's frame ends and the
+    two-iteration kernel begins (its last frame strip is cut off there): same potentials."""
+    H, W, D = 22, 520, 128
+    left, right = random_pair(H, W, seed=31)
+    phi0 = random_phi(H, W, D, "f32", seed=5)
+    ref = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    monkeypatch.setenv("DS_FUSED2_LEFT", left_cols)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    monkeypatch.delenv("DS_FUSED2_LEFT")
+    assert g.fused2_info()["available"] and g.fused2_info()["cols"][0] > ref.fused2_info()["cols"][0]
+    for x in (ref, g):
+        x.set_phi(phi0)
+        x.iterate(4)
+        x.iterate(3)
+    assert g.fused2_info()["steps"] == 3
+    assert np.array_equal(g.get_phi(), ref.get_phi())
+    ref.close()
+    g.close()
