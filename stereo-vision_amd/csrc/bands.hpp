@@ -15,8 +15,11 @@
 // updates the interior rows runs on the handle's stream.  The two are ordered by two events
 // only: the boundary chain of iteration n waits for the interior kernel of iteration n - 1
 // (ev_main) and the interior kernel of iteration n + 1 waits for the chain of iteration n
-// (ev_side).  Both streams have the default priority.  RCCL's kernel is queued on the boundary
-// stream itself, so no third stream and no cycle of waits exists: main -> side -> main.
+// (ev_side).  A two-iteration step adds `frame_stream` for the frame's launches, which no
+// exchange waits for (band_fused2_step), tied to the boundary stream by two more events and
+// joined into the handle's stream at the end of the step.  All streams have the default
+// priority.  RCCL's kernel is queued on the boundary stream itself; every wait is for work
+// queued earlier in program order, so no cycle of waits exists.
 #pragma once
 #include <chrono>
 #include <cstdio>
