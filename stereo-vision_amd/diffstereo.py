@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libdiffstereo.so")
+LIB_PATH = os.environ.get("DS_LIBRARY") or os.path.join(HERE, "csrc", "libdiffstereo.so")  # DS_LIBRARY: another build
 DS_F32, DS_F64 = 0, 1
 _DTYPES = {"f32": (DS_F32, np.float32), "f64": (DS_F64, np.float64)}
 
