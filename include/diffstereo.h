@@ -150,12 +150,12 @@ int ds_energy(ds_handle *h, double *energy, double *max_residual);
 
 /* ds_energy for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The reduction's
- * partial sums live in a static device array of the library (64 MiB per GPU, held until the
+ * partial sums live in a static device array of the library (32 MiB per GPU, held until the
  * process ends) instead of the handle's buffers; the call allocates nothing, copies nothing and
  * does not synchronise: it queues four kernels on the handle's stream, the last of which writes
  * result_dev[0] = energy and result_dev[1] = max |f_t(d)|.  result_dev: two doubles of device
  * memory or pinned host memory, owned by the caller (anything else is DS_ERR_ARG).
- * Limit: the handle may need at most 4 194 304 partial sums (2 x blocks per row x rows of the
+ * Limit: the handle may need at most 2 097 152 partial sums (2 x blocks per row x rows of the
  * band: a whole 3840 x 2160 x 256 image needs 2 073 600); larger handles get DS_ERR_ARG.
  * All calls on one GPU share the array: calls that overlap in time on one GPU (two handles
  * on different streams) race; calls on one stream, or ordered by the caller, do not.
@@ -178,7 +178,14 @@ int ds_labels(ds_handle *h, int mode, uint32_t *out);
  * DS_ERR_STATE).  labels: [H][W], 0xffffffff where a pixel lost every label; alive_out
  * (optional): [H][W][D] bytes, the reference's `vertices`; *not_empty = is_not_empty();
  * *passes = relaxation passes run.  Whole-image handles only.
- * The comparisons run in the handle's precision.  On an f32 handle an epsilon below
+ * The comparisons run in the handle's precision, with the penalties evaluated as the sweep
+ * evaluates them (prefix / suffix minima), not in the reference's expression order: a vertex or
+ * edge whose gap differs from epsilon by less than the rounding of those sums (a few ulp of the
+ * potentials' size) may fall on the other side of the threshold than in the reference.  That
+ * matters only for an epsilon that is itself one of the gaps -- the candidates of epsilon search
+ * (ds_epsilon_gaps yields them exactly, in f64, in the reference's order): the search's
+ * predicate is then reproduced up to that rounding, i.e. the epsilon found may be a neighbour
+ * in the sorted array of the one the reference finds.  On an f32 handle an epsilon below
  * 2^-23 * (255 + lambda * (D - 1)) -- the spacing of f32 numbers at the size the potentials
  * reach -- is DS_ERR_ARG (ds_co_begin likewise): the reference's own default, 1 / (10 W H),
  * needs an f64 handle from about 50 x 50 pixels on. */
@@ -199,6 +206,10 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
  * so no other pixel can have a choice later): one small launch per such pixel, and after a
  * choice relaxation passes over a window that grows by one pixel per pass around it -- the
  * same masks as whole-image passes, since a deletion can only follow one at a neighbour.
+ * Masks left short of their fixed point (ds_co_pass stopped while it still reported changes) are
+ * first relaxed to it with whole-image passes.  max_passes bounds each of these loops; a window
+ * pass carries a deletion one pixel further, a whole-image pass (in place, raster order of
+ * blocks) usually further, so a bound tuned for ds_crossing_out may be too tight here.
  * Whole-image handles only. */
 int ds_find_best_labeling(ds_handle *h, int max_passes, uint32_t *labels, int *not_empty, long long *choices);
 
@@ -373,9 +384,13 @@ int ds_fused2_info(const ds_handle *h, int *available, int *col_begin, int *col_
 int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_begin, int *row_end);
 
 /* Replaces DiffusionGraph::box_blur (diffusion_stereo/src/diffusion_graph.rs:399-424), the
- * post-filter of a disparity map (unused by the reference's main).  disparity_map: [H][W] on the
- * host; out: [H][W] of 64-bit values (the reference's usize).  The arithmetic is that of a
- * release build of the crate, where usize subtraction wraps: the window is rows [i - r, i + r) x
+ * post-filter of a disparity map (unused by the reference's main).  PARITY UNPINNED: the
+ * reference has no test, fixture or caller for box_blur, so what is reproduced is a reading of
+ * its source text, checked against values worked out by hand from that text, nothing more.
+ * disparity_map: [H][W] on the host; out: [H][W] of 64-bit values (the reference's usize).  The
+ * source subtracts usize values that can be smaller than what is subtracted; the arithmetic
+ * chosen here is that of a release build of the crate, where such a subtraction wraps (the
+ * crate's README recommends the release build): the window is rows [i - r, i + r) x
  * columns [j - r, j + r) and is empty for i < r or j < r (such pixels keep value * 255 /
  * normalization_term); a neighbour counts iff centre <= value <= centre + threshold; out =
  * (centre + sum of counted values) * 255 / ((1 + count) * normalization_term), integer division.

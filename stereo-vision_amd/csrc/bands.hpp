@@ -60,7 +60,13 @@ RcclApi *rccl()
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.dl) return &g_rccl;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // DS_RCCL_LIBRARY names the one file to load instead (another build of RCCL; a name that does
+    // not exist makes every ds_comm_* call fail cleanly, which is how the tests reach that path)
+    const char *override_name = std::getenv("DS_RCCL_LIBRARY");
+    const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::vector<const char *> names;
+    if (override_name && *override_name) names.push_back(override_name);
+    else names.assign(std::begin(defaults), std::end(defaults));
     void *dl = nullptr;
     for (const char *n : names)
         if ((dl = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
@@ -68,7 +74,8 @@ RcclApi *rccl()
         for (const char *n : names)
             if ((dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!dl) {
-        g_rccl.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+        const char *why = dlerror();  // one call: it returns the text once and clears it
+        g_rccl.err = std::string("librccl not found: ") + (why ? why : "dlopen failed");
         return nullptr;
     }
     auto sym = [&](const char *name) {
@@ -578,7 +585,8 @@ int ds_band_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t 
         HIPCHK(h, hipMemcpyAsync(flags, h->co_flags, sizeof flags, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         ++done;
-        if (flags[1] || !flags[0]) break;  // some band lost a pixel, or no band changed: the same on every rank
+        h->co_fixed = flags[1] || !flags[0];
+        if (h->co_fixed) break;  // some band lost a pixel, or no band changed: the same on every rank
         if (done >= max_passes) return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
         rc = exchange_masks(h);
         if (rc != DS_OK) return rc;

@@ -32,10 +32,11 @@ constexpr int kReduceBlocks = 1024;  // first-stage blocks of the energy reducti
 // Scratch of ds_energy_static: the energy reduction's partials in memory that exists from load
 // time, so that the call allocates nothing.  Layout (doubles): [0, kStaticPartials) block sums,
 // then kReduceBlocks first-stage sums, then the same two ranges for the maxima.  Every GPU the
-// library runs on holds its own copy (64 MiB) until the process ends.  In host code the array's
+// library runs on holds its own copy (32 MiB: room for a whole 3840 x 2160 x 256 image's
+// 2 073 600 partial sums, no more) until the process ends.  In host code the array's
 // name is only a handle for hipGetSymbolAddress: kernels and memsets get the per-device address
 // kept in g_scratch_ptr.
-constexpr long long kStaticPartials = 1ll << 22;
+constexpr long long kStaticPartials = 1ll << 21;
 constexpr long long kStaticDoubles = 2 * (kStaticPartials + kReduceBlocks);
 static __device__ __align__(256) double scratch[kStaticDoubles];
 
@@ -103,6 +104,7 @@ struct ds_handle {
     long long *co_state = nullptr;                    // co_fix_kernel's report, [2]
     double co_epsilon = 0.0;
     bool co_begun = false;
+    bool co_fixed = false;                            // the last relaxation pass deleted nothing (or emptied the graph)
     double *eps_buf[2] = {nullptr, nullptr};          // epsilon gaps: values and the sort's second buffer
     double *eps_sorted = nullptr;                     // one of eps_buf: sorted, duplicates removed
     size_t eps_count = 0;
@@ -520,7 +522,6 @@ void plan_fused2(ds_handle *h)
     const char *e = std::getenv("DS_FUSED2");
     if (e && std::strcmp(e, "off") == 0) return;
     if (h->dtype != DS_F32 || h->fused_waves != 16 || g.D != 4 * h->lpp) return;
-    p.waves = 16;
     p.waves = 12;
     if (const char *w = std::getenv("DS_F2_WAVES")) p.waves = std::atoi(w) == 16 ? 16 : 12;  // tuning knob
     const int FC1 = 2 * (16 * (64 / h->lpp) - 1);                 // the one-iteration kernel's strip
@@ -1672,6 +1673,7 @@ int ds_co_begin(ds_handle *h, double epsilon)
         h->co_flags = static_cast<int *>(flags);
     }
     h->co_epsilon = epsilon;
+    h->co_fixed = false;
     const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
     HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
     // Halo rows start all-alive: until the neighbouring band's rows arrive they must not
@@ -1746,6 +1748,7 @@ int ds_co_pass(ds_handle *h, int *changed, int *lost)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *changed = host_flags[0];
     *lost = host_flags[1];
+    h->co_fixed = !host_flags[0] || host_flags[1];
     return DS_OK;
 }
 
@@ -1848,6 +1851,16 @@ int ds_find_best_labeling(ds_handle *h, int max_passes, uint32_t *labels, int *n
     const long long total = (long long)g.H * g.W;
     long long chosen = 0;
     int ok = 1;
+    // The windows below follow one choice's consequences outwards; that equals whole-image passes
+    // only if nothing else is pending.  Masks that a caller stepped with ds_co_pass and left short
+    // of their fixed point are relaxed over the whole image first.
+    for (int done = 0; !h->co_fixed; ++done) {
+        if (done >= max_passes)
+            return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
+        int changed = 0, lost = 0;
+        rc = ds_co_pass(h, &changed, &lost);
+        if (rc != DS_OK) return rc;
+    }
     const char *wenv = std::getenv("DS_LABELING_WINDOW");
     const bool whole_passes = wenv && std::strcmp(wenv, "off") == 0;  // checking knob: whole-image passes
     const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);

@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <optional>
 #include <string>
 
 #include <unistd.h>
@@ -59,8 +60,20 @@ stereo::Matrix run_bands(stereo::RankGroup &group, const stereo::PgmImage &left,
     const std::size_t base = H / world, extra = H % world;
     const std::size_t rb = rank * base + std::min<std::size_t>(rank, extra), re = rb + base + ((std::size_t)rank < extra ? 1 : 0);
     const int device = share_gpu ? 0 : rank;
-    DiffusionGraph graph = DiffusionGraph::initialize_band(left.matrix, right.matrix, max_disparity, smoothing, dtype,
-                                                           rb, re, device);
+    // Every step that one rank alone can fail at (no such device, out of memory) is followed by
+    // an agreement over the sockets: a rank must not enter a collective -- the communicator's
+    // creation, an exchange -- that a failed rank will never join.
+    std::string failure;
+    std::optional<DiffusionGraph> made_graph;
+    try {
+        made_graph.emplace(DiffusionGraph::initialize_band(left.matrix, right.matrix, max_disparity, smoothing, dtype, rb,
+                                                           re, device));
+    } catch (const std::exception &e) {
+        failure = e.what();
+    }
+    if (!group.agree(made_graph.has_value()))
+        throw std::runtime_error(made_graph ? "another rank could not set up its band" : failure);
+    DiffusionGraph graph = std::move(*made_graph);
     ds_comm *comm = nullptr;
     ds_transport host{};
     if (rccl) {
@@ -69,8 +82,12 @@ stereo::Matrix run_bands(stereo::RankGroup &group, const stereo::PgmImage &left,
         group.broadcast(&ok, sizeof ok);
         if (!ok) throw std::runtime_error(std::string("RCCL: ") + ds_comm_last_error(nullptr));
         group.broadcast(id, sizeof id);
-        if (ds_comm_create(id, rank, world, device, &comm) != DS_OK)
-            throw std::runtime_error(std::string("RCCL: ") + ds_comm_last_error(nullptr));
+        const bool made = ds_comm_create(id, rank, world, device, &comm) == DS_OK;
+        if (!made) failure = std::string("RCCL: ") + ds_comm_last_error(nullptr);
+        if (!group.agree(made)) {
+            ds_comm_destroy(comm);
+            throw std::runtime_error(made ? "another rank could not join the communicator" : failure);
+        }
         graph.attach(comm, group.up(), group.down());
     } else {
         host = group.host_transport();
@@ -194,14 +211,15 @@ int main(int argc, char **argv)
                 if (group.rank() == 0) std::printf("Epsilon: %g\n", epsilon);
                 const Matrix map = run_bands(group, left, right, max_disparity, smoothing, dtype, epsilon, batch,
                                              max_batches, verbose, rccl, share_gpu);
-                status = 0;
                 if (group.rank() == 0) {
                     std::printf("Disparity map is consistent: %s\n", check_disparity_map(map) ? "true" : "false");
                     pgm_writer(map, out_path, max_disparity);
                     std::printf("Disparity map is saved to `%s`\n", out_path.c_str());
                 }
+                status = 0;  // rank 0: only once the map is on disk
             } catch (const std::exception &e) {
                 std::fprintf(stderr, "error (rank %d): %s\n", group.rank(), e.what());
+                if (group.rank() == 0) group.terminate_children();  // they may wait for this rank in a collective
             }
             std::fflush(stdout);
             if (group.rank() != 0) _exit(status);  // children: no atexit handlers of the parent's state

@@ -6,6 +6,7 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <csignal>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -139,12 +140,68 @@ std::vector<std::vector<std::uint8_t>> RankGroup::gather(const void *data, std::
     return out;
 }
 
+bool RankGroup::agree(bool ok)
+{
+    if (world_ == 1) return ok;
+    std::uint8_t all = ok ? 1 : 0;
+    if (rank_ == 0) {
+        for (int r = 1; r < world_; ++r) {
+            std::uint8_t theirs = 0;
+            try {
+                read_all(spoke_fd_[r], &theirs, 1);
+            } catch (const std::exception &) {
+                theirs = 0;  // the rank is gone
+            }
+            all = all && theirs;
+        }
+        for (int r = 1; r < world_; ++r) {
+            try {
+                write_all(spoke_fd_[r], &all, 1);
+            } catch (const std::exception &) {
+            }
+        }
+    } else {
+        try {
+            write_all(hub_fd_, &all, 1);
+            read_all(hub_fd_, &all, 1);
+        } catch (const std::exception &) {
+            all = 0;  // rank 0 is gone
+        }
+    }
+    return all != 0;
+}
+
+void RankGroup::terminate_children()
+{
+    for (int pid : children_) (void)kill((pid_t)pid, SIGTERM);
+}
+
 int RankGroup::wait_children()
 {
     int bad = 0;
-    for (int pid : children_) {
+    std::size_t left = children_.size();
+    while (left > 0) {
         int status = 0;
-        if (waitpid((pid_t)pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) bad = 1;
+        const pid_t pid = waitpid(-1, &status, 0);
+        if (pid < 0) {
+            if (errno == EINTR) continue;
+            bad = 1;  // no child left to wait for although some were expected
+            break;
+        }
+        bool mine = false;
+        for (int &c : children_)
+            if (c == (int)pid) {
+                c = -1;
+                mine = true;
+            }
+        if (!mine) continue;
+        --left;
+        if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+            if (!bad)
+                for (int c : children_)
+                    if (c > 0) (void)kill((pid_t)c, SIGTERM);
+            bad = 1;
+        }
     }
     children_.clear();
     return bad;

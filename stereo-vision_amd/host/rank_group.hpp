@@ -34,8 +34,16 @@ public:
     void broadcast(void *data, std::size_t bytes);                      // from rank 0 to all
     // rank 0 receives every rank's block (rank order, its own first); sizes may differ
     std::vector<std::vector<std::uint8_t>> gather(const void *data, std::size_t bytes);
-    // rank 0: waits for the children; returns 0 if all exited with status 0
+    // Collective: true on every rank iff every rank passed true.  A rank that dies instead of
+    // calling it counts as false (its socket reads as closed), so the others leave together
+    // before they enter a collective the dead rank would never join.
+    bool agree(bool ok);
+    // rank 0: waits for the children in the order they exit; as soon as one ends badly the
+    // others get SIGTERM (they may be waiting in a collective for the one that is gone).
+    // Returns 0 if all exited with status 0.
     int wait_children();
+    // rank 0: SIGTERM to every child still running (rank 0 itself has failed)
+    void terminate_children();
 
     // Halo rows and reductions through these sockets and host memory (blocking).
     ds_transport host_transport();

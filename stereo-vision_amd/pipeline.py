@@ -138,13 +138,17 @@ def main(argv=None):
     ap.add_argument("--labeling", choices=("simple", "best"), default="simple")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args(argv)
+    # ROCr reads this when the runtime starts, i.e. at the first HIP call of the process: set it
+    # before anything can make one.  (The host driver only supports dmabuf IPC; without the
+    # setting RCCL's buffer sharing between ranks fails.  A caller that has initialised the GPU
+    # before calling main() must have exported it itself.)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo")  # control plane; --backend chooses how halo rows travel
     rank = dist.get_rank() if world > 1 else 0
     try:

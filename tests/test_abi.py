@@ -70,3 +70,26 @@ def test_python_binding_has_no_cpu_fallback(monkeypatch):
     src = open(os.path.join(ROOT, "stereo-vision_amd", "diffstereo.py")).read()
     src += open(os.path.join(ROOT, "stereo-vision_amd", "bands.py")).read()
     assert "oracle" not in src.replace("CPU oracle", "")
+
+
+def test_missing_librccl_is_an_error_code_not_a_crash():
+    """ds_comm_* on a host where librccl cannot be loaded: DS_ERR_STATE with a text, twice in a
+    row (the loader's message can only be read once).  A child process: the lookup is cached."""
+    code = (
+        "import ctypes as C, sys\n"
+        "lib = C.CDLL(sys.argv[1])\n"
+        "lib.ds_comm_last_error.restype = C.c_char_p\n"
+        "ident = (C.c_uint8 * 128)()\n"
+        "for _ in range(2):\n"
+        "    rc = lib.ds_comm_unique_id(ident)\n"
+        "    text = lib.ds_comm_last_error(None)\n"
+        "    assert rc == -3, rc\n"
+        "    assert b'librccl not found' in text, text\n"
+        "comm = C.c_void_p()\n"
+        "assert lib.ds_comm_create(ident, 0, 1, 0, C.byref(comm)) == -3\n"
+        "assert comm.value is None\n"
+        "print('ok')\n"
+    )
+    env = dict(os.environ, DS_RCCL_LIBRARY="/nonexistent/librccl-not-here.so")
+    out = subprocess.run(["python3", "-c", code, diffstereo.LIB_PATH], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr

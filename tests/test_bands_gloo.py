@@ -1,6 +1,7 @@
-"""Row-band partition + halo exchange (stereo-vision_amd/bands.py) on CPU ranks over
-gloo, with the CPU oracle as the compute engine: every rank's band must end bit-identical
-to the unpartitioned run, and the all-reduced energy must equal the whole image's."""
+"""Row-band partition (stereo-vision_amd/bands.py) and the band protocol as tests/band_runner.py
+states it, on CPU ranks over gloo with the CPU oracle as the compute engine: every rank's band
+must end bit-identical to the unpartitioned run, and the all-reduced energy must equal the
+whole image's."""
 import os
 import socket
 
@@ -13,6 +14,7 @@ import torch.multiprocessing as mp
 from __graft_entry__ import load_package
 from oracle.pyoracle import FastOracle
 from tests.band_oracle_engine import OracleBandEngine
+from tests.band_runner import BandRunner
 from tests.util import NumpyCrossingOut, random_pair, random_phi
 
 load_package()
@@ -55,7 +57,7 @@ def _worker(rank, world, port, H, W, D, iters, out):
         rb, re = bands.partition_rows(H, world)[rank]
         eng = OracleBandEngine(left, right, D, 1.2, rb, re)
         eng.set_rows(phi0, rb, re)         # own rows only: halos must come from the exchange
-        runner = bands.BandRunner(eng)
+        runner = BandRunner(eng)
         runner.exchange_all()
         runner.iterate(iters)
         energy = runner.energy()
@@ -95,7 +97,7 @@ def _co_worker(rank, world, port, H, W, D, iters, eps, out):
         rb, re = bands.partition_rows(H, world)[rank]
         eng = OracleBandEngine(left, right, D, 1.2, rb, re)
         eng.set_rows(np.zeros((H, W, 4, D)), rb, re)
-        runner = bands.BandRunner(eng)
+        runner = BandRunner(eng)
         runner.exchange_all()
         runner.iterate(iters)
         got = runner.crossing_out(eps, with_mask=True)

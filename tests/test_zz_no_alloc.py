@@ -77,15 +77,15 @@ def test_energy_static_rejects_what_it_cannot_take(monkeypatch):
     g.synchronize()
     assert out.read() == g.energy(with_residual=True)
     g.close()
-    # a handle beyond the scratch's 4 194 304 partial sums: 2 x 256 blocks per row x 8200 rows
+    # a handle beyond the scratch's 2 097 152 partial sums: 2 x 256 blocks per row x 4200 rows
     monkeypatch.setenv("DS_PLACEMENT", "off")
     rng = np.random.default_rng(0)
-    H, W = 8200, 16384
+    H, W = 4200, 16384
     left = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
     wide = diffstereo.DiffusionGraph(left, left, 1, 1.2, dtype="f32")
     with pytest.raises(diffstereo.DiffStereoError) as err:
         wide.energy_static(out.ptr.value)
-    assert err.value.code == -1 and "4194304" in str(err.value)
+    assert err.value.code == -1 and "2097152" in str(err.value)
     assert wide.energy() == 0.0  # the allocating entry point takes it (identical images, D = 1)
     wide.close()
     out.free()
