@@ -11,15 +11,22 @@ per GPU, with one halo row exchanged per neighbour after each colour (RCCL
 send/recv): total work is fixed, so scaling is strong.
 
 Prints ONE JSON line on rank 0: metric = valid (pixel, label) pairs x iterations per
-second for the whole job, plus `roofline` (sweep kernel against the 8 TB/s HBM peak,
-from HIP events around every launch in the timed region) and `cpu_baseline` (the
-faithful single-threaded CPU restatement of the reference rule, timed on this host on
-a bounded crop of the same workload).
+second for the whole job, plus `roofline` (the dominant kernel against the 8 TB/s HBM peak,
+from HIP events around every launch in the timed region; for N > 1 the slowest rank's, with
+every rank's account in `per_rank`) and, at N = 1, `cpu_baseline` (the faithful
+single-threaded CPU restatement of the reference rule, timed on this host on a bounded crop
+of the same workload), `sustained` (the same handle over a few seconds: a kernel bound by
+the vector ALU follows the clock the GPU holds) and `f64` (the same workload in the
+reference's own precision).
 """
 import argparse
 import ctypes as C
 import json
 import os
+
+# ROCr reads this when the runtime starts (the first HIP call of the process): set before torch
+# can make one.  The host driver only supports dmabuf IPC; RCCL's buffer sharing needs it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import socket
 import subprocess
 import sys
@@ -189,16 +196,92 @@ def spawn_ranks(n):
     return status
 
 
+def kernel_account(graph, steps, dtype, D, H, W, workload, world):
+    """After profile_end: this rank's launches of the timed region by kind and the `roofline`
+    object of its dominant kernel (algorithmic bytes of that kernel's launches / the HIP-event
+    time of those launches)."""
+    rb, re = graph.row_begin, graph.row_end
+    elem = 4 if dtype == "f32" else 8
+    my_pl = valid_pairs(re - rb, W, D)
+    tname = "float" if dtype == "f32" else "double"
+    lpp = 16 if D <= 64 else 32 if D <= 128 else 64
+    n = [0, 0, 0]
+    ms = [0.0, 0.0, 0.0]
+    for kind in range(3):
+        n[kind], ms[kind] = graph.profile_kind(kind)
+    f2 = graph.fused2_info()
+    n2, ms2 = n[2], ms[2]
+    if n2:
+        # Two iterations per launch over the interior: per (pixel, label) of that region and per
+        # launch, 4 rows of the second colour read + 4 written (4*sizeof(T), half the pixels are
+        # of that colour) + the cost byte of both iterations.
+        bytes_per_pl = 4 * elem + 2
+        kernel = "ds::fused2_iteration_kernel<%s, %d, 12>" % (tname, lpp)
+        kernel_s, launches, per_launch = ms2 / 1e3, n2, 2
+        # valid (pixel, label) pairs of the interior region: column j has min(j, D - 1) + 1 labels
+        units_per_launch = (sum(min(j, D - 1) + 1 for j in range(f2["cols"][0], f2["cols"][1]))
+                            * (f2["rows"][1] - f2["rows"][0]))
+        note = ("one launch = TWO iterations over the interior (columns %d-%d, rows %d-%d); it moves "
+                "(4*sizeof(T)+2)/2 B per valid pixel*label*iteration and is bound by the vector ALU, not by "
+                "HBM: frac is what the metric asks for (algorithmic bytes / time / HBM peak), "
+                "frac_at_one_iteration_bytes prices the same time with the one-iteration kernel's "
+                "4*sizeof(T)+1 B per iteration, frac_at_two_pass_bytes with the half-sweeps' 8*sizeof(T)+1 B. "
+                "The frame around the interior runs through the one-iteration kernel beside it "
+                "(other_launches)" % (f2["cols"] + f2["rows"]))
+    elif n[1]:
+        # Whole iterations in one kernel: only the second colour's phi moves (4 rows read, 4 written
+        # per pixel of that colour = 4*sizeof(T) per (pixel, label)) plus every pixel's cost byte.
+        bytes_per_pl = 4 * elem + 1
+        kernel = "ds::fused_iteration_kernel<%s, %d, %d, false>" % (tname, lpp, 16 if dtype == "f32" else 8)
+        kernel_s, launches, per_launch = ms[1] / 1e3, n[1], 1
+        # one launch = one iteration over the rows the kernel updates: all of them on one GPU, all
+        # but the rows next to a neighbouring band otherwise (those go through half-sweeps)
+        fb, fe = graph.fused_rows()
+        whole = rb == 0 and re == H
+        units_per_launch = my_pl if whole else my_pl * (fe - fb) / float(re - rb)
+        note = ("one launch = one whole iteration that moves only the second colour's phi (4*sizeof(T)+1 B per "
+                "valid pixel*label); priced with the two half-sweeps' 8*sizeof(T)+1 B the same time reads "
+                "frac_at_two_pass_bytes")
+    else:
+        bytes_per_pl = 8 * elem + 1       # each phi row read once + written once, u8 cost read once
+        kernel = "ds::sweep_kernel<%s, %d, false>" % (tname, lpp)
+        kernel_s, launches, per_launch = ms[0] / 1e3, n[0], 0.5
+        units_per_launch = my_pl * steps * 1.0 / max(launches, 1)  # a colour (or part of it) per launch
+        note = "one launch = one colour's half-sweep"
+    achieved = bytes_per_pl * units_per_launch * launches / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    avg_launch_s = kernel_s / max(launches, 1)
+    pmc_bytes = pmc_traffic(workload, kernel) if world == 1 else None
+    scale = (2 if n2 else 1) * units_per_launch * launches / kernel_s / 1e9 / HBM_PEAK_GBS if kernel_s > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_bytes / avg_launch_s / 1e9 if pmc_bytes and avg_launch_s > 0 else None,
+                "traffic_bytes_per_launch": pmc_bytes,
+                "kernel": kernel,
+                "algorithmic_bytes_per_pixel_label": bytes_per_pl,
+                "iterations_per_launch": per_launch,
+                "two_pass_bytes_per_pixel_label": 8 * elem + 1,
+                "frac_at_two_pass_bytes": (8 * elem + 1) * scale,
+                **({"frac_at_one_iteration_bytes": (4 * elem + 1) * scale} if n2 else {}),
+                "note": note,
+                "launches": launches,
+                "avg_launch_ms": avg_launch_s * 1e3,
+                "other_launches": {"half_sweeps": n[0], "half_sweeps_ms": ms[0],
+                                   "one_iteration_launches": n[1] if n2 else 0,
+                                   "one_iteration_ms": ms[1] if n2 else 0.0} if (n[1] or n2) else None,
+                "placement": dict(graph.placement_info(), mode=os.environ.get("DS_PLACEMENT", "default"))}
+    return n, ms, roofline
+
+
 def main():
-    # ds_create is outside the timed region and a benchmark iterates for long: let the library
-    # search for a placement of phi (include/diffstereo.h, ds_placement_info); reported in the line.
-    os.environ.setdefault("DS_PLACEMENT", "search")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k_256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companions", action="store_true",
+                    help="N = 1: leave out the sustained run and the f64 run that follow the timed steps")
+    ap.add_argument("--sustained-steps", type=int, default=400)
     ap.add_argument("--band-of", type=int, default=1,
                     help="with --gpus 1: time only band 0 of this many row bands, without halo exchange "
                          "(what one GPU of a larger job sweeps; a timing, not a result)")
@@ -221,7 +304,6 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # gloo is the control plane only (the communicator's id, barriers, the max over ranks);
         # the halo rows travel over RCCL inside the library
         # (gloo and RCCL report on stdout when they connect: keep that away from the one JSON line)
@@ -282,88 +364,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # First use, part of the set-up like ds_create: the two-iteration path allocates its third set of
-    # planes, chooses its row segments and loads its kernels at its first step.  Two iterations
-    # bring that about whatever --warmup says; the W warm-up steps the caller asked for follow.
-    runner.iterate(2)
-    fence()
-    runner.iterate(args.warmup)
-    fence()
-    # launches per step: a band has boundary half-sweeps + the interior kernel; a two-iteration
-    # step of the whole image has the interior kernel + eight launches for the frame around it
-    graph.profile_begin(args.steps * 8 + 16)
-    t0 = time.perf_counter()
-    runner.iterate(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = graph.profile_end()
-    my_elapsed = elapsed
+    def timed(run, g, steps, warmup):
+        """W warm-up steps, then `steps` steps between two fences; (seconds, launches timed)."""
+        # First use, part of the set-up like ds_create: the two-iteration path allocates its third
+        # set of planes, chooses its row segments and loads its kernels at its first step.  Two
+        # iterations bring that about whatever --warmup says; the W warm-up steps follow.
+        run.iterate(2)
+        fence()
+        run.iterate(warmup)
+        fence()
+        # launches per step: a band has boundary half-sweeps + the interior kernel; a two-iteration
+        # step has the interior kernel + the launches for the frame around it
+        g.profile_begin(steps * 8 + 16)
+        t0 = time.perf_counter()
+        run.iterate(steps)
+        fence()
+        dt = time.perf_counter() - t0
+        return dt, g.profile_end()
+
+    my_elapsed, prof = timed(runner, graph, args.steps, args.warmup)
+    elapsed = my_elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     energy = runner.energy()
-    # every rank's own account: its kernels by kind and what its wall time holds beyond them
-    # (exchanges and waiting for neighbours; the boundary chain runs beside the interior kernel)
-    mine = graph.profile_split()
-    fused_ms = mine["fused_ms"] / max(args.steps, 1)
-    sweeps_ms = mine["half_sweep_ms"] / max(args.steps, 1)
-    account = {"rank": rank, "rows": [rb, re], "wall_ms_per_step": my_elapsed / args.steps * 1e3,
-               "interior_kernel_ms_per_step": fused_ms, "half_sweeps_ms_per_step": sweeps_ms,
-               "launches": prof["launches"]}
+    # every rank's own account: its launches by kind (HIP events on the stream each launch is queued
+    # on: the interior kernel on the handle's stream, the frame's on the frame stream, the boundary
+    # rows' half-sweeps on the boundary stream -- the small ones include the time they wait for a
+    # compute unit the interior kernel holds) and what its wall time holds beyond the interior kernel
+    n_kind, ms_kind, my_roofline = kernel_account(graph, args.steps, dtype, D, H, W, args.workload, world)
+    per = 1.0 / max(args.steps, 1)
+    interior_ms = (ms_kind[2] if n_kind[2] else ms_kind[1]) * per
+    account = {"rank": rank, "rows": [rb, re], "wall_ms_per_step": my_elapsed * per * 1e3,
+               "interior_kernel_ms_per_step": interior_ms,
+               "interior_kernel": my_roofline["kernel"],
+               "two_iteration_launches": n_kind[2],
+               "frame_launches_ms_per_step": (ms_kind[1] * per) if n_kind[2] else 0.0,
+               "boundary_half_sweeps_ms_per_step": ms_kind[0] * per,
+               "exposed_beyond_interior_kernel_ms_per_step": my_elapsed * per * 1e3 - interior_ms,
+               "launches": prof["launches"], "roofline": my_roofline}
     per_rank = [account]
     if world > 1:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, account)
 
+    line = None
     if rank == 0:
         pl = valid_pairs(H, W, D) if args.band_of == 1 else valid_pairs(re - rb, W, D)
-        elem = 4 if dtype == "f32" else 8
-        my_pl = valid_pairs(re - rb, W, D)
-        split = mine
-        tname = "float" if dtype == "f32" else "double"
-        lpp = 16 if D <= 64 else 32 if D <= 128 else 64
-        n2, ms2 = graph.profile_kind(2)
-        f2 = graph.fused2_info()
-        note = None
-        if n2:
-            # Two iterations per launch over the interior (every label valid there): per (pixel,
-            # label) of that region and per launch, 4 rows of the second colour read + 4 written
-            # (4*sizeof(T), half the pixels are of that colour) + the cost byte of both iterations.
-            bytes_per_pl = 4 * elem + 2
-            kernel = "ds::fused2_iteration_kernel<%s, %d, 12>" % (tname, lpp)
-            kernel_s, launches = ms2 / 1e3, n2
-            # valid (pixel, label) pairs of the interior region: column j has min(j, D - 1) + 1 labels
-            units_per_launch = (sum(min(j, D - 1) + 1 for j in range(f2["cols"][0], f2["cols"][1]))
-                                * (f2["rows"][1] - f2["rows"][0]))
-            note = ("one launch = TWO iterations over the image's interior (columns %d-%d, rows %d-%d); it moves "
-                    "(4*sizeof(T)+2)/2 B per valid pixel*label*iteration and is bound by the vector ALU, not by "
-                    "HBM: frac is what the metric asks for (algorithmic bytes / time / HBM peak), "
-                    "frac_at_one_iteration_bytes prices the same time with the one-iteration kernel's "
-                    "4*sizeof(T)+1 B per iteration, frac_at_two_pass_bytes with the half-sweeps' 8*sizeof(T)+1 B. "
-                    "The frame around the interior runs through the one-iteration kernel beside it "
-                    "(other_launches)" % (f2["cols"] + f2["rows"]))
-        elif split["fused"]:
-            # Whole iterations in one kernel: only the second colour's phi moves (4 rows read,
-            # 4 written per pixel of that colour = 4*sizeof(T) per (pixel, label) of the image)
-            # plus every pixel's cost byte.  The half-sweeps that complete ds_iterate are
-            # reported beside it, not mixed into the kernel's rate.
-            bytes_per_pl = 4 * elem + 1
-            kernel = "ds::fused_iteration_kernel<%s, %d, %d, false>" % (tname, lpp, 16 if dtype == "f32" else 8)
-            kernel_s, launches = split["fused_ms"] / 1e3, split["fused"]
-            # one launch = one iteration over the rows the kernel updates: all of them on one GPU,
-            # all but the rows next to a neighbouring band otherwise (those go through half-sweeps)
-            fb, fe = graph.fused_rows()
-            whole = rb == 0 and re == H
-            units_per_launch = my_pl if whole else my_pl * (fe - fb) / float(re - rb)
-        else:
-            bytes_per_pl = 8 * elem + 1       # each phi row read once + written once, u8 cost read once
-            kernel = "ds::sweep_kernel<%s, %d, false>" % (tname, lpp)
-            kernel_s, launches = split["half_sweep_ms"] / 1e3, split["half_sweeps"]
-            units_per_launch = my_pl * args.steps * 1.0 / max(launches, 1)  # a colour (or part of it) per launch
-        achieved = bytes_per_pl * units_per_launch * launches / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        avg_launch_s = kernel_s / max(launches, 1)
-        pmc_bytes = pmc_traffic(args.workload, kernel) if world == 1 else None
+        slowest = max(per_rank, key=lambda a: a["wall_ms_per_step"])
+        roofline = dict(slowest["roofline"], rank=slowest["rank"])
         line = {
             "metric": "G pixel*label*iters/s (node), 4Kx256 disparities",
             "value": pl * args.steps / elapsed / 1e9,
@@ -378,39 +428,34 @@ def main():
                        "halo_exchange": transport,
                        **({"partial": "band 0 of %d (rows %d-%d) on one GPU, no halo exchange: timing only"
                            % (args.band_of, rb, re)} if args.band_of > 1 else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_bytes / avg_launch_s / 1e9 if pmc_bytes and avg_launch_s > 0 else None,
-                         "traffic_bytes_per_launch": pmc_bytes,
-                         "kernel": kernel,
-                         "algorithmic_bytes_per_pixel_label": bytes_per_pl,
-                         "iterations_per_launch": 2 if n2 else (1 if split["fused"] else 0.5),
-                         "two_pass_bytes_per_pixel_label": 8 * elem + 1,
-                         "frac_at_two_pass_bytes": (8 * elem + 1) * (2 if n2 else 1) * units_per_launch * launches
-                         / kernel_s / 1e9 / HBM_PEAK_GBS if kernel_s > 0 else 0.0,
-                         **({"frac_at_one_iteration_bytes": (4 * elem + 1) * 2 * units_per_launch * launches
-                             / kernel_s / 1e9 / HBM_PEAK_GBS} if n2 and kernel_s > 0 else {}),
-                         "note": note if n2 else
-                         ("one launch = one whole iteration that moves only the second colour's phi "
-                          "(4*sizeof(T)+1 B per valid pixel*label); priced with the two half-sweeps' "
-                          "8*sizeof(T)+1 B the same time reads frac_at_two_pass_bytes")
-                         if split["fused"] else "one launch = one colour's half-sweep",
-                         "launches": launches,
-                         "avg_launch_ms": avg_launch_s * 1e3,
-                         "other_launches": {"half_sweeps": split["half_sweeps"], "half_sweeps_ms": split["half_sweep_ms"],
-                                            "one_iteration_launches": split["fused"] if n2 else 0,
-                                            "one_iteration_ms": split["fused_ms"] if n2 else 0.0}
-                         if (split["fused"] or n2) else None,
-                         "rank": 0, "placement": dict(graph.placement_info(), mode=os.environ.get("DS_PLACEMENT"))},
+            "roofline": roofline,
             "energy": energy,
         }
         if world > 1:
-            line["per_rank"] = per_rank
+            line["per_rank"] = [{k: v for k, v in a.items() if k != "roofline"} for a in per_rank]
+
+    companions = world == 1 and args.band_of == 1 and not args.no_companions
+    if companions and args.sustained_steps > 0:
+        # the same handle for a few seconds: clock droop of a kernel bound by the vector ALU shows here
+        t0 = time.perf_counter()
+        runner.iterate(args.sustained_steps)
+        fence()
+        dt = time.perf_counter() - t0
+        line["sustained"] = {"steps": args.sustained_steps, "ms_per_step": dt / args.sustained_steps * 1e3,
+                             "value": valid_pairs(H, W, D) * args.sustained_steps / dt / 1e9, "seconds": dt}
+    graph.close()
+    if companions and dtype == "f32" and (args.workload + "_f64") in WORKLOADS:
+        # the same workload in the reference's own precision (one iteration per launch)
+        g64 = diffstereo.DiffusionGraph(left, right, D, lam, dtype="f64")
+        dt, _ = timed(SingleGpu(g64), g64, args.steps, args.warmup)
+        _, _, roof64 = kernel_account(g64, args.steps, "f64", D, H, W, args.workload + "_f64", 1)
+        line["f64"] = {"ms_per_step": dt / args.steps * 1e3, "value": valid_pairs(H, W, D) * args.steps / dt / 1e9,
+                       "steps": args.steps, "energy": g64.energy(), "roofline": roof64}
+        g64.close()
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(left, right, D, lam)
         print(json.dumps(line), flush=True)
-
-    graph.close()
     if world > 1:
         dist.destroy_process_group()
 

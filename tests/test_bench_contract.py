@@ -47,3 +47,6 @@ def test_bench_line_has_the_fields_the_driver_reads():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["value"] > 100 * c["value"]
+    # the companions of a one-GPU run: the same handle over several hundred steps
+    assert d["sustained"]["steps"] >= 400 and d["sustained"]["ms_per_step"] > 0
+    assert r["placement"]["mode"] == "default"   # the headline is timed as a default deployment runs

@@ -161,3 +161,57 @@ def test_rccl_self_exchange_matches_device_copies(dtype, D, rows, W):
     out = mgr.dict()
     mp.spawn(_rccl_worker, args=(dtype, D, rows, W, out), nprocs=1, join=True)
     assert out[0] == (True, True, True, True), out[0]
+
+
+def _wide_worker(rank, world, port, out):
+    """One of four bands of 270 rows of a 3840-wide image with 256 disparities, f32: the band
+    geometry of the 4K benchmark on eight GPUs (its widths, its strips, its unequal row segments)."""
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(280, exit=True, file=sys.stderr)
+    import torch
+    import torch.distributed as dist
+    load_package()
+    from stereo_vision_amd import bands, diffstereo, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        H, W, D, iters = 270 * world, 3840, 256, 7
+        left, right, _ = synth.synthetic_pair(H, W, D)
+        rb, re = bands.partition_rows(H, world)[rank]
+        g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32", row_begin=rb, row_end=re, device=0)
+        runner = bands.Bands(g, bands.GlooTransport(), rank, world)
+        runner.exchange_all()
+        runner.iterate(iters)                       # three two-iteration steps, then one iteration
+        steps = g.fused2_info()["steps"]
+        energy = runner.energy()                    # summed over the ranks
+        checksum = g.checksum()
+        edge = 6                                    # the band's first and last rows, where the three queues meet
+        top, bottom = g.get_phi(rb, rb + edge), g.get_phi(re - edge, re)
+        g.close()
+        dist.barrier()                              # every band is gone before the whole images come
+        whole = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+        whole.iterate(iters)
+        same = np.array_equal(top, whole.get_phi(rb, rb + edge)) and np.array_equal(bottom, whole.get_phi(re - edge, re))
+        e_ref = whole.energy()
+        out[rank] = (bool(same), abs(energy - e_ref) <= 1e-9 * max(1.0, abs(e_ref)), steps, checksum, whole.checksum())
+        whole.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bands_of_the_4k_benchmark_geometry():
+    """3840 x 1080 x 256, f32, four ranks sharing the GPU, seven iterations through ds_band_iterate
+    against ds_iterate on the whole image: every band's first and last six rows bit for bit, the
+    bands' checksums adding up to the image's (so every other row agrees too), the energy."""
+    import torch.multiprocessing as mp
+    world = 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_wide_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for rank in range(world):
+        assert out[rank][:2] == (True, True), "rank %d: %s" % (rank, out[rank])
+        assert out[rank][2] == 3, "rank %d ran %d two-iteration steps" % (rank, out[rank][2])
+    assert sum(out[rank][3] for rank in range(world)) % (1 << 64) == out[0][4]
