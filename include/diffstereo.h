@@ -415,6 +415,81 @@ int ds_placement_info(const ds_handle *h, int *tries, double *probe_ms, int *spl
  * all entries the reference would touch), to compare large states without copying. */
 int ds_checksum(ds_handle *h, uint64_t *out);
 
+/* ---- The superpixel variant: crate superpixel_stereo of the reference -------------------------
+ *
+ * The same diffusion on a coarser graph: the image is cut into windows of super_height x
+ * super_width pixels and each window holds two nodes, its pixels at or below the window's mean
+ * intensity and the others (superpixel_stereo/src/superpixels.rs:76-108).  A node has up to nine
+ * neighbour slots (utils.rs:29-35: 0 = the other node of its window, 1-2 / 3-4 / 5-6 / 7-8 = the
+ * two nodes of the left / upper / right / lower window), its data term is the sum of
+ * |L[i][j] - R[i][j - d]| over its pixels (diffusion_graph.rs:134-150), its labels are d <= the
+ * leftmost column of its pixels (:192-198), the pairwise term of an edge is
+ * perimeter * smoothing * |d - d'| with a weight per edge (:164-173), and the ordering constraint
+ * between horizontal neighbours is switched off (:199-205).  The crate is unfinished in the
+ * reference (not in its CI, its tests do not compile); what is reproduced is its source text:
+ * tests/test_sp_oracle_kat.py says, test by test, which of the crate's known answers that text
+ * reproduces.  Arrays at the boundary use the crate's layouts: potentials
+ * [windows down][windows across][2][9][D] (diffusion_graph.rs:44), edge_perimeters
+ * [windows down][windows across][2][9] (superpixels.rs:47), superpixels [H][W].  Entries the crate
+ * never touches read back as 0.  One handle = one GPU = the whole image (the graph of a
+ * 400 x 400 image in 5 x 5 windows, the crate's own working point, has 12 800 nodes).
+ * Same conventions as above (DS_OK / DS_ERR_*, ds_sp_last_error). */
+typedef struct ds_sp_handle ds_sp_handle;
+
+/* Replaces SuperpixelRepresentation::initialize + split_into_superpixels (superpixels.rs:58-108),
+ * calculate_edge_perimeters (:147-266) when perimeters != 0, and DiffusionGraph::initialize
+ * (diffusion_graph.rs:69-96).  perimeters == 0 leaves every weight 0, the state the crate's own
+ * tests run in.  With perimeters != 0 the weights are the crate's: the boundary length inside
+ * each window for slot 0, and 0 between windows -- its loops over a window's last column / row
+ * test `image_j + 1 < window end` there, which never holds (:195-213, 234-255).  Where the crate
+ * would index beyond the image in that function (:235 walks columns super_i * super_width ..,
+ * i.e. images with (windows down - 1) * super_width > W) the call fails with DS_ERR_ARG as the
+ * crate panics.  Windows that do not fit (H / super_height or W / super_width = 0): DS_ERR_ARG. */
+int ds_sp_create(const uint8_t *left, const uint8_t *right, int H, int W, int D, double lambda, int super_height,
+                 int super_width, int perimeters, int dtype, ds_sp_handle **out);
+void ds_sp_destroy(ds_sp_handle *h);
+const char *ds_sp_last_error(const ds_sp_handle *h);
+int ds_sp_info(const ds_sp_handle *h, int *windows_down, int *windows_across, int *D, int *dtype);
+
+/* The public fields superpixels (superpixels.rs:39; [H][W], 0 or 1, 0 outside every window) and
+ * edge_perimeters (:47); left_j_in_superpixel (:110-123) capped at D - 1 for every node,
+ * [windows down][windows across][2]; the data term per node and label,
+ * [windows down][windows across][2][D] (0 for labels beyond left_j). */
+int ds_sp_get_superpixels(ds_sp_handle *h, uint8_t *out);
+int ds_sp_get_perimeters(ds_sp_handle *h, double *out);
+int ds_sp_set_perimeters(ds_sp_handle *h, const double *in);
+int ds_sp_get_left_j(ds_sp_handle *h, int32_t *out);
+int ds_sp_get_cost(ds_sp_handle *h, uint32_t *out);
+
+/* The public field potentials (diffusion_graph.rs:44), element type float or double. */
+int ds_sp_get_phi(ds_sp_handle *h, void *out);
+int ds_sp_set_phi(ds_sp_handle *h, const void *in);
+
+/* Replaces n_iters calls of DiffusionGraph::diffusion_act (diffusion_graph.rs:357-482).
+ * schedule 0: four launches per iteration, one per colour 2 * ((window row + window column) & 1)
+ * + superpixel (nodes of one colour are never neighbours).  schedule 1: the crate's own order --
+ * windows in raster order, superpixel 0 then 1 -- as one launch per anti-diagonal of windows and
+ * superpixel (every node sees the operands the sequential loop gives it): the parity mode.
+ * Synchronous at return. */
+int ds_sp_iterate(ds_sp_handle *h, int n_iters, int schedule);
+
+/* Replaces DiffusionGraph::energy (diffusion_graph.rs:640-671). */
+int ds_sp_energy(ds_sp_handle *h, double *energy);
+
+/* Replaces build_depth_map (diffusion_graph.rs:513-548) without the file: per pixel the argmin_d
+ * f_t(d) of its node (min_penalty_vertex, :584-604, the first minimum); out [H][W]. */
+int ds_sp_labels(ds_sp_handle *h, uint32_t *out);
+
+/* Replaces CrossingOutGraph::initialize_with_epsilon + crossing_out + is_not_empty +
+ * simple_best_labeling (superpixel_stereo/src/crossing_out_graph.rs:72-236,240-312,397-480) on
+ * the current potentials.  Edge penalties are evaluated by brute force in f64 in the crate's
+ * expression order, so vertices and edges fall on the side of the thresholds where the crate
+ * puts them (on an f32 handle: for the f32 potentials converted to f64).  labels [H][W]
+ * (0xffffffff at pixels of a node without labels), alive_out (optional) = the crate's `vertices`
+ * [windows down][windows across][2][D]. */
+int ds_sp_crossing_out(ds_sp_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
+                       int *not_empty, int *passes);
+
 #ifdef __cplusplus
 }
 #endif

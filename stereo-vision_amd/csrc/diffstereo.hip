@@ -521,7 +521,11 @@ void plan_fused2(ds_handle *h)
     const ds::Geometry &g = h->g;
     const char *e = std::getenv("DS_FUSED2");
     if (e && std::strcmp(e, "off") == 0) return;
-    if (h->dtype != DS_F32 || h->fused_waves != 16 || g.D != 4 * h->lpp) return;
+    // D fills the lanes of a pixel slot (64 / 128 / 256), or fills the lower ones in whole lanes (a
+    // multiple of 4: the kernel's PARTIAL instantiation); other D keep one iteration per launch
+    if (h->dtype != DS_F32 || h->fused_waves != 16 || g.D % 4 != 0) return;
+    if (const char *pd = std::getenv("DS_FUSED2_PARTIAL"))  // checking knob: off = only D = 4 LPP
+        if (std::strcmp(pd, "off") == 0 && g.D != 4 * h->lpp) return;
     p.waves = 12;
     if (const char *w = std::getenv("DS_F2_WAVES")) p.waves = std::atoi(w) == 16 ? 16 : 12;  // tuning knob
     const int FC1 = 2 * (16 * (64 / h->lpp) - 1);                 // the one-iteration kernel's strip
@@ -676,10 +680,15 @@ int launch_fused2_interior(ds_handle *h)
     const dim3 grid(p.strips, segs), block(64 * p.waves);
     float *base = static_cast<float *>(h->phi);
     const float lambda = (float)h->lambda;
+    const bool partial = g.D != 4 * h->lpp;
     auto go = [&](auto lppc, auto wavesc) {
-        hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, decltype(lppc)::value, decltype(wavesc)::value>), grid, block,
-                           0, h->stream, in, base, base, np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg, table,
-                           h->store_first ? 1 : 0);
+        constexpr int L = decltype(lppc)::value, FW = decltype(wavesc)::value;
+        if (partial)
+            hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, L, FW, true>), grid, block, 0, h->stream, in, base, base,
+                               np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg, table, h->store_first ? 1 : 0);
+        else
+            hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, L, FW, false>), grid, block, 0, h->stream, in, base, base,
+                               np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg, table, h->store_first ? 1 : 0);
     };
     auto with_waves = [&](auto lppc) {
         if (p.waves == 12) go(lppc, std::integral_constant<int, 12>{});

@@ -63,9 +63,14 @@ template <int LPP> __device__ __forceinline__ void prefix_scans6(float x[6])
 }
 
 // rev4 = 4 * (63 - lane): the byte address ds_bpermute takes for the mirrored lane
-template <int LPP>
+// PARTIAL: the node's labels fill only the lower lanes of its segment (D < 4 LPP, D a multiple of
+// 4); lane_on says whether this lane holds labels.  The other lanes carry whatever arithmetic
+// leaves in them; all that reaches the lanes below is their contribution to the suffix minima
+// and the first of them as a lane's `next`, and both are put to +inf here.  (Prefix minima flow
+// upwards only.)
+template <int LPP, bool PARTIAL = false>
 __device__ __forceinline__ void messages_lean(const V4<float> psi[4], const float lam[4], float lam1, int lseg,
-                                              int rev4, V4<float> M[4])
+                                              int rev4, V4<float> M[4], bool lane_on = true)
 {
     using R = Real<float>;
     const float inf = R::inf();
@@ -80,7 +85,8 @@ __device__ __forceinline__ void messages_lean(const V4<float> psi[4], const floa
         }
         // the lane's own minimum: what the lanes above (prefix) / below (suffix) get from it
         const float pa = R::min(R::min(R::min(a[t][0], a[t][1]), a[t][2]), a[t][3]);
-        const float pb = R::min(R::min(R::min(b[t][3], b[t][2]), b[t][1]), b[t][0]);
+        float pb = R::min(R::min(R::min(b[t][3], b[t][2]), b[t][1]), b[t][0]);
+        if (PARTIAL) pb = lane_on ? pb : inf;
         // prefix: exclusive, so shift one lane up first
         float up = dpp<DPP_WAVE_SHR1>(inf, pa);
         if (LPP < 64) up = (lseg == 0) ? inf : up;
@@ -109,7 +115,7 @@ __device__ __forceinline__ void messages_lean(const V4<float> psi[4], const floa
         }
     }
     float prev = dpp<DPP_WAVE_SHR1>(inf, psi[0].v[3]);
-    float next = dpp<DPP_WAVE_SHL1>(inf, psi[2].v[0]);
+    float next = dpp<DPP_WAVE_SHL1>(inf, PARTIAL ? (lane_on ? psi[2].v[0] : inf) : psi[2].v[0]);
     if (LPP < 64) {
         prev = (lseg == 0) ? inf : prev;
         next = (lseg == LPP - 1) ? inf : next;
@@ -136,7 +142,11 @@ struct RowSegments {
     int begin[17];
 };
 
-template <typename T, int LPP, int FW>
+// PARTIAL (f32 only): D < 4 LPP, D a multiple of 4.  The lanes of a slot beyond its D / 4 label
+// lanes load from clamped addresses, store nothing and keep out of the other lanes' minima
+// (messages_lean); everything else is the D = 4 LPP kernel.  A separate instantiation, so that
+// kernel's code does not change.
+template <typename T, int LPP, int FW, bool PARTIAL = false>
 __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, const T *__restrict__ phi,
                                                                    T *__restrict__ phi_out, FusedPlanes np,
                                                                    const uint8_t *__restrict__ cost, T lambda,
@@ -149,7 +159,12 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     __shared__ Fused2Lds<T, NP, DL> lds;
     const T inf = R::inf();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
+    const int q = lane / LPP, lseg = lane % LPP;
+    // d0: the lane's first label as an address (PARTIAL: clamped into the slot's row); lane_on: the
+    // lane holds labels
+    const bool lane_on = !PARTIAL || 4 * lseg < g.Dpad;
+    const int d0 = PARTIAL ? (4 * lseg < g.Dpad ? 4 * lseg : g.Dpad - 4) : 4 * lseg;
+    const int dl = 4 * lseg;  // the lane's place in an LDS row
     const int kp = wave * PPW + q;
     // the slots of this wavefront, as scalars: a stage skips a wavefront none of whose slots it
     // needs (the strip narrows by one slot per stage), every wavefront still reaches the barrier
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     const int rev4 = 4 * (63 - lane);
     T lam[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(d0 + c);
+    for (int c = 0; c < 4; ++c) lam[c] = lambda * (T)(dl + c);
     const int c0 = col_begin - 2 + (int)blockIdx.x * FC2;
     const int a = c0 - 1 + 2 * kp;  // first column of the slot's pair (odd)
     int r0 = row_begin + (int)blockIdx.y * rows_per_seg;
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     auto update = [&](const V psi[4], uint32_t cost_word, int j, V out[4]) {
         V M[4];
         const V qc = unpack_cost<T>(cost_word);
-        if constexpr (sizeof(T) == 4) messages_lean<LPP>(psi, lam, lambda, lseg, rev4, M);
+        if constexpr (sizeof(T) == 4) messages_lean<LPP, PARTIAL>(psi, lam, lambda, lseg, rev4, M, lane_on);
         else messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         if (few_labels) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const bool valid = d0 + c <= j;
+                const bool valid = dl + c <= j;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) out[n].v[c] = valid ? out[n].v[c] : inf;
             }
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         update(psi, pre_cost, P ? a : a + 1, out);
         // odd row: red at a, its right neighbour is the slot's own black pixel, its left one the
         // previous slot's; even row: mirrored
-        store4(&lds.ring1[P][kp][d0], P ? out[0] : out[2]);
+        store4(&lds.ring1[P][kp][dl], P ? out[0] : out[2]);
         a_side_next = P ? out[2] : out[0];
         a_up_next = out[1];
         a_down_next = out[3];
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         const int j = P ? a + 1 : a;
         if (P ? wave_first > NP - 2 : wave_last < 1) return;  // no stage uses this slot's black pixel of this row
         V psi[4], out[4];
-        const V across = load4(&lds.ring1[P][P ? kr : kl][d0]);
+        const V across = load4(&lds.ring1[P][P ? kr : kl][dl]);
         psi[0] = P ? a_side_cur : across;
         psi[1] = a_down_prev;
         psi[2] = P ? across : a_side_cur;
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         update(psi, cost_word(cost_black, i, j), j, out);
         // odd row: black at a + 1, its left neighbour is the slot's own red pixel, its right one the
         // next slot's
-        store4(&lds.ring2[P][kp][d0], P ? out[2] : out[0]);
+        store4(&lds.ring2[P][kp][dl], P ? out[2] : out[0]);
         b_side_next = P ? out[0] : out[2];
         b_up_next = out[1];
         b_down_next = out[3];
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         const int j = P ? a : a + 1;
         if (wave_last < 1 || wave_first > NP - 2) return;  // stage D takes nothing from the outermost slots
         V psi[4], out[4];
-        const V across = load4(&lds.ring2[P][P ? kl : kr][d0]);
+        const V across = load4(&lds.ring2[P][P ? kl : kr][dl]);
         psi[0] = P ? across : b_side_cur;
         psi[1] = b_down_prev;
         psi[2] = P ? b_side_cur : across;
@@ -264,12 +279,12 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         // the last launch of a call also stores the first colour of iteration n+2: the block's own
         // rows, the strip's own columns (odd row: the red pixels of slots 2 .. NP - 2, even row:
         // 1 .. NP - 3); nothing reads those planes while iterations run
-        if (store_first && r >= r0 && r < r1 && (P ? (kp >= 2 && kp <= NP - 2) : (kp >= 1 && kp <= NP - 3))) {
+        if (store_first && lane_on && r >= r0 && r < r1 && (P ? (kp >= 2 && kp <= NP - 2) : (kp >= 1 && kp <= NP - 3))) {
             const long long own = (long long)(r - g.row0 + 1) * g.row_stride + (long long)(j >> 1) * g.Dpad + d0;
 #pragma unroll
             for (int n = 0; n < 4; ++n) st4_nt(phi_out + g.plane_off[0][n] + own, out[n]);
         }
-        store4(&lds.ring3[P][kp][d0], P ? out[0] : out[2]);
+        store4(&lds.ring3[P][kp][dl], P ? out[0] : out[2]);
         c_side_next = P ? out[2] : out[0];
         c_up_next = out[1];
         c_down_next = out[3];
@@ -280,13 +295,13 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         const bool mine = P ? (kp >= 1 && kp <= NP - 3) : (kp >= 2 && kp <= NP - 2);
         if (P ? (wave_last < 1 || wave_first > NP - 3) : (wave_last < 2 || wave_first > NP - 2)) return;
         V psi[4], out[4];
-        const V across = load4(&lds.ring3[P][P ? kr : kl][d0]);
+        const V across = load4(&lds.ring3[P][P ? kr : kl][dl]);
         psi[0] = P ? c_side_cur : across;
         psi[1] = c_down_prev;
         psi[2] = P ? across : c_side_cur;
         psi[3] = c_up_next;
         update(psi, cost_word(cost_black, i, j), j, out);
-        if (mine) {
+        if (mine && lane_on) {
             const long long own = (long long)(i - g.row0 + 1) * g.row_stride + (long long)(j >> 1) * g.Dpad + d0;
 #pragma unroll
             for (int n = 0; n < 4; ++n) st4_nt(phi_out + np.out_off[n] + own, out[n]);

@@ -74,6 +74,22 @@ SYMBOLS = {
     "ds_box_blur": (_I, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "ds_placement_info": (_I, [_P, _IP, _DP, _IP]),
     "ds_checksum": (_I, [_P, C.POINTER(C.c_uint64)]),
+    # the superpixel variant (superpixel.py)
+    "ds_sp_create": (_I, [_P, _P, _I, _I, _I, _D, _I, _I, _I, _I, _PP]),
+    "ds_sp_destroy": (None, [_P]),
+    "ds_sp_last_error": (C.c_char_p, [_P]),
+    "ds_sp_info": (_I, [_P, _IP, _IP, _IP, _IP]),
+    "ds_sp_get_superpixels": (_I, [_P, _P]),
+    "ds_sp_get_perimeters": (_I, [_P, _P]),
+    "ds_sp_set_perimeters": (_I, [_P, _P]),
+    "ds_sp_get_left_j": (_I, [_P, _P]),
+    "ds_sp_get_cost": (_I, [_P, _P]),
+    "ds_sp_get_phi": (_I, [_P, _P]),
+    "ds_sp_set_phi": (_I, [_P, _P]),
+    "ds_sp_iterate": (_I, [_P, _I, _I]),
+    "ds_sp_energy": (_I, [_P, _DP]),
+    "ds_sp_labels": (_I, [_P, _P]),
+    "ds_sp_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
 }
 
 # struct ds_transport (include/diffstereo.h): a host-supplied way to move halo rows
