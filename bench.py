@@ -216,11 +216,14 @@ def kernel_account(graph, steps, dtype, D, H, W, workload, world):
         # launch, 4 rows of the second colour read + 4 written (4*sizeof(T), half the pixels are
         # of that colour) + the cost byte of both iterations.
         bytes_per_pl = 4 * elem + 2
-        kernel = "ds::fused2_iteration_kernel<%s, %d, 12>" % (tname, lpp)
+        kernel = "ds::fused2_iteration_kernel<%s, %d, 12, %s>" % (tname, lpp, "false" if D == 4 * lpp else "true")
         kernel_s, launches, per_launch = ms2 / 1e3, n2, 2
-        # valid (pixel, label) pairs of the interior region: column j has min(j, D - 1) + 1 labels
+        # valid (pixel, label) pairs of the interior region: column j has min(j, D - 1) + 1 labels.
+        # A step covers the region once: in one launch, or (deep-halo bands) in up to three
+        # launches over disjoint rows, so the units of a launch are the region's over launches per step
+        per_step = n2 / max(steps // 2, 1)
         units_per_launch = (sum(min(j, D - 1) + 1 for j in range(f2["cols"][0], f2["cols"][1]))
-                            * (f2["rows"][1] - f2["rows"][0]))
+                            * (f2["rows"][1] - f2["rows"][0])) / per_step
         note = ("one launch = TWO iterations over the interior (columns %d-%d, rows %d-%d); it moves "
                 "(4*sizeof(T)+2)/2 B per valid pixel*label*iteration and is bound by the vector ALU, not by "
                 "HBM: frac is what the metric asks for (algorithmic bytes / time / HBM peak), "
@@ -265,6 +268,7 @@ def kernel_account(graph, steps, dtype, D, H, W, workload, world):
                 "note": note,
                 "launches": launches,
                 "avg_launch_ms": avg_launch_s * 1e3,
+                "band_halo": os.environ.get("DS_BAND_HALO", "one-row") if world > 1 else None,
                 "other_launches": {"half_sweeps": n[0], "half_sweeps_ms": ms[0],
                                    "one_iteration_launches": n[1] if n2 else 0,
                                    "one_iteration_ms": ms[1] if n2 else 0.0} if (n[1] or n2) else None,

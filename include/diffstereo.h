@@ -322,7 +322,22 @@ const char *ds_comm_last_error(const ds_comm *c);
 /* Tells a band handle how its halo rows travel and who its neighbours are: up_rank owns the
  * band above, down_rank the band below, -1 = none (the image's edge).  ds_band_attach_comm
  * uses the library's RCCL transport (the communicator must outlive the handle's use of it);
- * ds_band_attach copies the given table.  Creates the handle's boundary stream and events. */
+ * ds_band_attach copies the given table.  Creates the handle's boundary stream and events.
+ * Collective when the band has a neighbour: the ranks agree (two one-word reductions through
+ * the transport) that all bands run the same halo protocol, DS_ERR_STATE otherwise.
+ *
+ * Halo depth.  By default a band keeps one halo row per neighbour and a two-iteration step
+ * exchanges one row four times, each exchange depending on the one before.  With
+ * DS_BAND_HALO=deep in the environment at ds_create_band, an f32 band of 16 rows or more (with
+ * an interior for the two-iteration kernel, and 4 rows or more of image beyond it wherever it
+ * has a neighbour) keeps FOUR rows of each neighbouring band: the two-iteration kernel then takes
+ * every row of the band itself and a step needs ONE grouped exchange (four rows of the second
+ * colour's four planes per neighbour: 31.5 MB at 4K x 256 against 4 x 2 MB), queued behind the
+ * band's first and last four rows and running beside the next step's long launch.  Same results,
+ * bit for bit.  On such a handle the entry points for hosts that sequence a band themselves
+ * (ds_sweep, ds_sweep_pair, ds_sweep_next, ds_iterate_rows, ds_finish_iterations, ds_halo,
+ * ds_halo_next) return DS_ERR_STATE; every other entry point sees the band's own rows as on any
+ * band. */
 int ds_band_attach_comm(ds_handle *h, ds_comm *c, int up_rank, int down_rank);
 int ds_band_attach(ds_handle *h, const ds_transport *t, int up_rank, int down_rank);
 

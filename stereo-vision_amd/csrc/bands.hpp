@@ -176,8 +176,10 @@ int need_attached(ds_handle *h, const char *who)
 void halo_row(const ds_handle *h, const long long *planes, int side, int which, void **ptr, size_t *bytes)
 {
     const ds::Geometry &g = h->g;
+    const int own_rows = own_end(h) - own_begin(h);
     const int slot = side == 0 ? (which == 0 ? 1 : 3) : (which == 0 ? 3 : 1);
-    const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
+    // rows of the stored planes: 0 = the halo row above the stored rows, ext_up + 1 = the band's first own row
+    const int il = h->ext_up + (side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? own_rows : own_rows + 1));
     *ptr = static_cast<char *>(h->phi) + (size_t)(planes[slot] + (long long)il * g.row_stride) * h->elem;
     *bytes = (size_t)g.Wh * g.Dpad * h->elem;
 }
@@ -337,6 +339,150 @@ int band_fused2_step(ds_handle *h)
     return DS_OK;
 }
 
+// ---- deep halo: one exchange per two-iteration step -----------------------------------------
+//
+// Two iterations reach four rows: the second colour of iteration n + 2 at row i is a function of
+// the second colour of iteration n at rows i - 4 .. i + 4 (and of nothing else: the first colour
+// is a function of the second).  A deep-halo band stores three rows of each neighbouring band
+// beyond its own (plus the usual halo row: four rows of the second colour's planes, all four
+// slots), so the two-iteration kernel takes every own row of the band itself -- no half-sweeps
+// of boundary rows, no exchange in the middle of a step -- and the only communication of a step
+// is ONE grouped exchange of those four rows with each neighbour: 4 slots x 4 rows per
+// direction (31.5 MB at 4K x 256 f32) where the one-row protocol moves 4 x 1 row in four
+// dependent exchanges.  The stored rows beyond the own rows are the stored band's frame: the
+// kernels run over them as over any band and leave stale values there, which the next
+// exchange overwrites with the neighbour's.
+//
+// Order inside a step (o0, o1 = the own rows; X the current planes, Z the ones produced):
+//   handle's stream   the kernel over rows [o0 + 4, o1 - 4): reads own rows of X only, so it
+//                     starts at once -- the exchange of the step before is still in flight
+//   frame stream      the column frame (one-iteration kernel, X -> Y -> Z) over the same rows,
+//                     and at the image's top / bottom the rows the two-iteration kernel leaves out
+//   boundary stream   behind the exchange of the step before (stream order): the column frame
+//                     and the two-iteration kernel over rows [o0, o0 + 4) and [o1 - 4, o1), which
+//                     read the halo rows; then an event (all of the step's compute on this
+//                     stream is queued before it); then the exchange of these very rows of Z
+// The handle's stream joins the frame stream and that event, not the exchange, so the next
+// step's long launch and the exchange become runnable at the same moment.  All waits are for
+// work queued earlier; no priorities.
+void *plane_row(const ds_handle *h, long long plane, int image_row)
+{
+    return static_cast<char *>(h->phi) +
+           (size_t)(plane + (long long)(image_row - h->g.row0 + 1) * h->g.row_stride) * h->elem;
+}
+
+int exchange_deep(ds_handle *h, const long long *planes, hipStream_t stream)
+{
+    int peers[8], n = 0;
+    void *send[8], *recv[8];
+    size_t bytes[8];
+    const int o0 = own_begin(h), o1 = own_end(h);
+    for (int side = 0; side < 2; ++side) {
+        const int peer = side == 0 ? h->up : h->down;
+        if (peer < 0) continue;
+        for (int slot = 0; slot < 4; ++slot) {
+            peers[n] = peer;
+            send[n] = plane_row(h, planes[slot], side == 0 ? o0 : o1 - 4);
+            recv[n] = plane_row(h, planes[slot], side == 0 ? o0 - 4 : o1);
+            bytes[n] = (size_t)(4 * h->g.row_stride) * h->elem;
+            ++n;
+        }
+    }
+    if (n == 0) return DS_OK;
+    if (h->transport.exchange(h->transport.ctx, n, peers, send, recv, bytes, stream) != 0)
+        return transport_fail(h, "the deep halo exchange");
+    return DS_OK;
+}
+
+int band_deep_step(ds_handle *h)
+{
+    ds::Geometry &g = h->g;
+    const ds_handle::Fused2Plan &p = h->plan2;
+    const int o0 = own_begin(h), o1 = own_end(h);
+    const bool up = h->up >= 0, down = h->down >= 0;
+    const long long *X = g.plane_off[1], *Y = h->y_off, *Z = h->alt_off;
+    const int all = (g.W + p.strip1 - 1) / p.strip1;
+    // rows of the long launch; next to a neighbour p.rT == o0 and p.rB == o1
+    const int m0 = up ? o0 + 4 : p.rT, m1 = down ? o1 - 4 : p.rB;
+    const int c0 = up ? m0 - 2 : p.rT + 2, c1 = down ? m1 + 2 : p.rB - 2;  // the column frame's first pass beside it
+    const bool last = h->store_first;  // the call's last step: second passes and the kernel store the first colour
+    int rc = need_frame_stream(h);
+    if (rc == DS_OK) rc = order_streams(h, h->stream, h->ev_main, h->frame_stream);
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_main, 0));
+    // frame stream: what reads no halo row
+    rc = on_stream(h, h->frame_stream, [&]() -> int {
+        FrameRegion first[4] = {{0, p.left1, c0, c1}, {p.right1_begin, p.right1, c0, c1}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        FrameRegion second[4] = {{0, p.left2, m0, m1, p.cL}, {p.cR, p.right2, m0, m1}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        int n = 2;
+        if (!up) {
+            first[n] = {0, all, o0, p.rT + 2};
+            second[n++] = {0, all, o0, p.rT};
+        }
+        if (!down) {
+            first[n] = {0, all, p.rB - 2, o1};
+            second[n++] = {0, all, p.rB, o1};
+        }
+        h->store_first = false;
+        int r = launch_fused_regions(h, X, Y, first, n, 1);
+        h->store_first = last;
+        if (r != DS_OK) return r;
+        HIPCHK(h, hipEventRecord(h->ev_rows, h->frame_stream));
+        return launch_fused_regions(h, Y, Z, second, n, 1);
+    });
+    if (rc == DS_OK) rc = launch_fused2_rows(h, m0, m1);
+    if (rc != DS_OK) return rc;
+    // boundary stream: what reads the halo rows, then the exchange of what it made
+    rc = on_side_stream(h, [&]() -> int {
+        FrameRegion first[4], second[4];
+        int n = 0;
+        if (up) {
+            first[n] = {0, p.left1, o0 - 2, m0 - 2};
+            second[n++] = {0, p.left2, o0, m0, p.cL};
+            first[n] = {p.right1_begin, p.right1, o0 - 2, m0 - 2};
+            second[n++] = {p.cR, p.right2, o0, m0};
+        }
+        if (down) {
+            first[n] = {0, p.left1, m1 + 2, o1 + 2};
+            second[n++] = {0, p.left2, m1, o1, p.cL};
+            first[n] = {p.right1_begin, p.right1, m1 + 2, o1 + 2};
+            second[n++] = {p.cR, p.right2, m1, o1};
+        }
+        h->store_first = false;
+        int r = launch_fused_regions(h, X, Y, first, n, 1);
+        h->store_first = last;
+        if (r == DS_OK && up) r = launch_fused2_rows(h, o0, m0);
+        if (r == DS_OK && down) r = launch_fused2_rows(h, m1, o1);
+        if (r != DS_OK) return r;
+        HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_rows, 0));  // the second pass reads rows of the frame stream's first
+        r = launch_fused_regions(h, Y, Z, second, n, 1);
+        if (r != DS_OK) return r;
+        HIPCHK(h, hipEventRecord(h->ev_side, h->side_stream));
+        return exchange_deep(h, Z, h->side_stream);
+    });
+    if (rc != DS_OK) return rc;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_side, 0));
+    rc = order_streams(h, h->frame_stream, h->ev_frame, h->stream);
+    if (rc != DS_OK) return rc;
+    for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
+    h->fused_pending = !h->store_first;
+    return DS_OK;
+}
+
+// One iteration of a deep-halo band (the odd one of a call): the one-iteration kernel over all
+// stored rows it can take; its reach is two rows, so every own row comes out right.  It reads the
+// halo rows, so it waits for the exchange of the step before, and its own exchange follows it.
+int band_deep_single(ds_handle *h)
+{
+    int fb = 0, fe = 0;
+    fused_safe_rows(h, &fb, &fe);
+    int rc = order_streams(h, h->side_stream, h->ev_side, h->stream);
+    if (rc == DS_OK) rc = launch_fused(h, fb, fe);
+    if (rc == DS_OK) rc = order_streams(h, h->stream, h->ev_main, h->side_stream);
+    if (rc == DS_OK) rc = exchange_deep(h, h->g.plane_off[1], h->side_stream);
+    return rc;
+}
+
 int reduce_scalar(ds_handle *h, void *dev, int count, int kind)
 {
     if (h->up < 0 && h->down < 0) return DS_OK;  // a single band
@@ -348,7 +494,7 @@ int reduce_scalar(ds_handle *h, void *dev, int count, int kind)
 // Mask halo rows of the crossing-out, both colours, to both neighbours, in one group.
 int exchange_masks(ds_handle *h)
 {
-    const ds::Geometry &g = h->g;
+    const ds::Geometry g = own_view(h);
     int peers[4], n = 0;
     void *send[4], *recv[4];
     size_t bytes[4];
@@ -465,6 +611,28 @@ int ds_band_attach(ds_handle *h, const ds_transport *t, int up_rank, int down_ra
     h->up = up_rank;
     h->down = down_rank;
     h->attached = true;
+    // Neighbouring bands must run the same protocol (a deep-halo band exchanges four rows of four
+    // planes per step, the others one row four times): the minimum and the maximum of "deep" over
+    // all ranks must agree.
+    if (up_rank >= 0 || down_rank >= 0) {
+        int lo = h->deep ? 1 : 0, hi = lo;
+        for (int pass = 0; pass < 2; ++pass) {
+            int *v = pass == 0 ? &lo : &hi;
+            HIPCHK(h, hipMemcpyAsync(h->d_flag, v, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            rc = reduce_scalar(h, h->d_flag, 1, pass == 0 ? DS_REDUCE_MIN_I32 : DS_REDUCE_MAX_I32);
+            if (rc != DS_OK) return rc;
+            HIPCHK(h, hipMemcpyAsync(v, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        if (lo != hi) {
+            h->attached = false;
+            return fail(h, DS_ERR_STATE,
+                        "the bands disagree on DS_BAND_HALO=deep: every band must be created with it, be an f32 band of 16 "
+                        "rows or more, four rows or more away from the image's other edge, and have an interior for the "
+                        "two-iteration kernel");
+        }
+    }
     return DS_OK;
 }
 
@@ -489,6 +657,7 @@ int ds_band_exchange(ds_handle *h)
     if (rc == DS_OK) rc = need_current(h, "ds_band_exchange");
     if (rc == DS_OK) rc = use_device(h);
     for (int colour = 0; colour < 2 && rc == DS_OK; ++colour) rc = exchange_phi(h, colour, false, h->stream);
+    if (rc == DS_OK && h->deep) rc = exchange_deep(h, h->g.plane_off[1], h->stream);
     if (rc != DS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DS_OK;
@@ -508,6 +677,34 @@ int ds_band_iterate(ds_handle *h, int n_iters)
     if (h->fused_waves) fused_safe_rows(h, &fb, &fe);
     const bool fused = n_iters > 0 && fe - fb >= 4 && g.Hb >= 8;
     const auto host_begin = std::chrono::steady_clock::now();
+    if (h->deep && n_iters > 0) {
+        // two iterations per step with one exchange each; an odd iteration runs alone.  The call's
+        // last launches store the first colour of the own rows; its one halo row per neighbour
+        // follows in an exchange of its own, so that every other entry point finds both colours'
+        // halo rows current, as after the one-row protocol.
+        if (!prepare_fused2(h)) return fail(h, DS_ERR_NOMEM, "a deep-halo band needs the two-iteration kernel's third set of planes");
+        int left = n_iters;
+        for (; left >= 2 && rc == DS_OK; left -= 2) {
+            h->store_first = left == 2;
+            rc = band_deep_step(h);
+            ++h->fused2_steps;
+        }
+        if (left == 1 && rc == DS_OK) {
+            h->store_first = true;
+            rc = band_deep_single(h);
+        }
+        h->store_first = false;
+        const hipError_t d1 = hipStreamSynchronize(h->side_stream), d2 = hipStreamSynchronize(h->stream);
+        const hipError_t d3 = h->frame_stream ? hipStreamSynchronize(h->frame_stream) : hipSuccess;
+        if (rc != DS_OK) return rc;
+        if (d1 != hipSuccess) return fail_hip(h, "hipStreamSynchronize(boundary stream)", d1);
+        if (d2 != hipSuccess) return fail_hip(h, "hipStreamSynchronize", d2);
+        if (d3 != hipSuccess) return fail_hip(h, "hipStreamSynchronize(frame stream)", d3);
+        rc = exchange_phi(h, 0, false, h->stream);
+        if (rc != DS_OK) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return DS_OK;
+    }
     if (fused) {
         // two iterations per step while more than two remain (the last one runs alone: see ds_iterate)
         // as in ds_iterate: the call's last launches also store the first colour (the band's first /

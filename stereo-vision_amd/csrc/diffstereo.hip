@@ -75,11 +75,14 @@ struct ds_handle {
         // the frame's column regions, in strips of the one-iteration kernel: first iteration
         // (widened by two columns towards the interior) and second
         int left1 = 0, left2 = 0, right1_begin = 0, right1 = 0, right2 = 0;
-        // row segments of the interior launch, chosen at its first launch (launch_fused2_interior)
-        bool segmented = false;
-        int segs = 0;
-        int seg_begin[17] = {};  // unequal segments when seg_count > 0
-        int seg_count = 0;
+        // row segments of the launches of the two-iteration kernel, chosen when a row range is first
+        // launched (launch_fused2_rows): the whole interior, or its parts in a deep-halo step
+        struct Segments {
+            int row_begin = 0, row_end = 0, segs = 0;
+            int seg_begin[17] = {};  // unequal segments when seg_count > 0
+            int seg_count = 0;
+        } cached[4];
+        int cached_n = 0;
     } plan2;
     void *phi_y = nullptr;
     long long y_off[4] = {0, 0, 0, 0};
@@ -108,6 +111,13 @@ struct ds_handle {
     double *eps_buf[2] = {nullptr, nullptr};          // epsilon gaps: values and the sort's second buffer
     double *eps_sorted = nullptr;                     // one of eps_buf: sorted, duplicates removed
     size_t eps_count = 0;
+
+    // Deep halo (DS_BAND_HALO=deep, bands.hpp): the handle stores ext_up / ext_down rows of the
+    // neighbouring bands beyond its own rows (3 next to a neighbour), so that g describes rows
+    // [own rows - ext_up, own rows + ext_down) and every kernel that takes g works on them
+    // unchanged; what a caller sees as "the band" is own_view().  Both 0 on every other handle.
+    int ext_up = 0, ext_down = 0;
+    bool deep = false;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     // set around the last launch(es) of ds_iterate: the fused kernels then store the first colour
@@ -199,6 +209,24 @@ int use_device(ds_handle *h)
     return DS_OK;
 }
 
+// The band's own rows as a geometry of their own: the same planes, entered ext_up rows further
+// down.  Equal to h->g unless the handle stores rows of its neighbours (deep halo).
+ds::Geometry own_view(const ds_handle *h)
+{
+    ds::Geometry v = h->g;
+    v.row0 = h->g.row0 + h->ext_up;
+    v.Hb = h->g.Hb - h->ext_up - h->ext_down;
+    for (int c = 0; c < 2; ++c)
+        for (int s = 0; s < 4; ++s) v.plane_off[c][s] += (long long)h->ext_up * h->g.row_stride;
+    return v;
+}
+// the packed cost of the own rows (the colour stride stays the stored band's)
+const uint8_t *own_cost(const ds_handle *h) { return h->cost_px + (size_t)h->ext_up * h->g.Wh * h->g.Dpad; }
+int own_begin(const ds_handle *h) { return h->g.row0 + h->ext_up; }
+int own_end(const ds_handle *h) { return h->g.row0 + h->g.Hb - h->ext_down; }
+
+int not_deep(ds_handle *h, const char *who);
+
 // Address of the current device's copy of `scratch`, looked up once per device.
 int scratch_for_device(ds_handle *h, int device, double **out)
 {
@@ -211,6 +239,16 @@ int scratch_for_device(ds_handle *h, int device, double **out)
         g_scratch_ptr[device] = static_cast<double *>(p);
     }
     if (out) *out = g_scratch_ptr[device];
+    return DS_OK;
+}
+
+// The entry points with which a host sequences a band's half-sweeps and halo rows itself work on
+// one halo row; a deep-halo handle runs its protocol inside ds_band_iterate only.
+int not_deep(ds_handle *h, const char *who)
+{
+    if (h->deep)
+        return fail(h, DS_ERR_STATE, std::string(who) + ": this band was created with DS_BAND_HALO=deep; "
+                                     "use ds_band_iterate / ds_band_exchange");
     return DS_OK;
 }
 
@@ -557,7 +595,8 @@ void plan_fused2(ds_handle *h)
     p.ok = p.strips >= 1 && p.rB - p.rT >= 8;
 }
 
-int launch_fused2_interior(ds_handle *h);
+int launch_fused2_rows(ds_handle *h, int row_begin, int row_end);
+int launch_fused2_interior(ds_handle *h) { return launch_fused2_rows(h, h->plan2.rT, h->plan2.rB); }
 
 int fused2_step(ds_handle *h)
 {
@@ -597,14 +636,18 @@ int fused2_step(ds_handle *h)
     return DS_OK;
 }
 
-// The two-iteration kernel over the handle's interior: current second-colour planes -> the
-// alternate set, on the handle's stream.
-int launch_fused2_interior(ds_handle *h)
+// The two-iteration kernel over rows [row_begin, row_end) of the handle's interior (all of its
+// columns): current second-colour planes -> the alternate set, on the handle's stream.
+int launch_fused2_rows(ds_handle *h, int row_begin, int row_end)
 {
     ds::Geometry &g = h->g;
     ds_handle::Fused2Plan &p = h->plan2;
     const long long *Z = h->alt_off;
-    const int rows = p.rB - p.rT;
+    const int rows = row_end - row_begin;
+    if (rows <= 0) return DS_OK;
+    ds_handle::Fused2Plan::Segments *cache = nullptr;
+    for (int k = 0; k < p.cached_n; ++k)
+        if (p.cached[k].row_begin == row_begin && p.cached[k].row_end == row_end) cache = &p.cached[k];
     // Row segments: about 96 rows each (a segment recomputes five rows of the first stages).  One
     // block fills a CU (157 registers x 12 wavefronts), so the grid runs in rounds of cu_count
     // blocks, and when that leaves only a few rounds (a band, a small image) equal segments waste
@@ -617,10 +660,10 @@ int launch_fused2_interior(ds_handle *h)
     // stream's small launches more often than once per round.
     int segs = (rows + 95) / 96;
     ds::RowSegments table{};
-    if (p.segmented) {
-        segs = p.segs;
-        table.n = p.seg_count;
-        for (int i = 0; i <= p.seg_count; ++i) table.begin[i] = p.seg_begin[i];
+    if (cache) {
+        segs = cache->segs;
+        table.n = cache->seg_count;
+        for (int i = 0; i <= cache->seg_count; ++i) table.begin[i] = cache->seg_begin[i];
     } else if ((long long)p.strips * segs < 4ll * h->cu_count && !std::getenv("DS_FUSED2_ROWS")) {
         long long best = -1;
         std::vector<long long> cu((size_t)h->cu_count);
@@ -652,18 +695,20 @@ int launch_fused2_interior(ds_handle *h)
                 if (best < 0 || span < best) {
                     best = span;
                     table.n = k;
-                    table.begin[0] = p.rT;
+                    table.begin[0] = row_begin;
                     for (int i = 0; i < k; ++i) table.begin[i + 1] = table.begin[i] + len[i];
                 }
             }
         }
         if (table.n > 0) segs = table.n;
     }
-    if (!p.segmented) {  // the search above costs milliseconds: once per handle
-        p.segmented = true;
-        p.segs = segs;
-        p.seg_count = table.n;
-        for (int i = 0; i <= table.n; ++i) p.seg_begin[i] = table.begin[i];
+    if (!cache && p.cached_n < 4) {  // the search above costs milliseconds: once per handle and row range
+        cache = &p.cached[p.cached_n++];
+        cache->row_begin = row_begin;
+        cache->row_end = row_end;
+        cache->segs = segs;
+        cache->seg_count = table.n;
+        for (int i = 0; i <= table.n; ++i) cache->seg_begin[i] = table.begin[i];
     }
     if (const char *e = std::getenv("DS_FUSED2_ROWS"))  // tuning knob: rows per segment
         if (std::atoi(e) > 0) segs = (rows + std::atoi(e) - 1) / std::atoi(e);
@@ -685,10 +730,10 @@ int launch_fused2_interior(ds_handle *h)
         constexpr int L = decltype(lppc)::value, FW = decltype(wavesc)::value;
         if (partial)
             hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, L, FW, true>), grid, block, 0, h->stream, in, base, base,
-                               np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg, table, h->store_first ? 1 : 0);
+                               np, h->cost_px, lambda, p.cL, row_begin, row_end, rows_per_seg, table, h->store_first ? 1 : 0);
         else
             hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, L, FW, false>), grid, block, 0, h->stream, in, base, base,
-                               np, h->cost_px, lambda, p.cL, p.rT, p.rB, rows_per_seg, table, h->store_first ? 1 : 0);
+                               np, h->cost_px, lambda, p.cL, row_begin, row_end, rows_per_seg, table, h->store_first ? 1 : 0);
     };
     auto with_waves = [&](auto lppc) {
         if (p.waves == 12) go(lppc, std::integral_constant<int, 12>{});
@@ -980,15 +1025,30 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     g.H = H; g.W = W; g.D = D;
     g.Dpad = (D + 3) & ~3;
     g.Wh = (W + 1) / 2;
-    g.row0 = row_begin;
-    g.Hb = row_end - row_begin;
     h->elem = dtype == DS_F64 ? 8 : 4;
     g.row_stride = (long long)g.Wh * g.Dpad;
-    h->plane_elems = (long long)(g.Hb + 2) * g.row_stride;
-    g.cost_colour_stride = (long long)g.Hb * g.Wh * g.Dpad;
     h->dtype = dtype;
     h->lambda = lambda;
     h->lpp = g.Dpad <= 64 ? 16 : g.Dpad <= 128 ? 32 : 64;
+    // Deep halo (band_deep_step in bands.hpp): a band that steps by two iterations keeps three more
+    // rows of each neighbouring band than the one halo row, so that one exchange per step is all it
+    // needs.  Asked for with DS_BAND_HALO=deep; taken if the band and its neighbours are tall enough
+    // and the band has an interior for the two-iteration kernel (checked below, once the plan exists).
+    {
+        const char *mode = std::getenv("DS_BAND_HALO");
+        const bool band = row_begin > 0 || row_end < H;
+        h->deep = mode && std::strcmp(mode, "deep") == 0 && band && dtype == DS_F32 &&
+                  (row_begin == 0 || row_begin >= 4) && (row_end == H || H - row_end >= 4) && row_end - row_begin >= 16;
+    }
+    auto set_rows = [&]() {
+        h->ext_up = h->deep && row_begin > 0 ? 3 : 0;
+        h->ext_down = h->deep && row_end < H ? 3 : 0;
+        g.row0 = row_begin - h->ext_up;
+        g.Hb = row_end - row_begin + h->ext_up + h->ext_down;
+        h->plane_elems = (long long)(g.Hb + 2) * g.row_stride;
+        g.cost_colour_stride = (long long)g.Hb * g.Wh * g.Dpad;
+    };
+    set_rows();
     {
         // Wavefronts per block of the fused iteration kernel.  f32 (95 VGPRs): 16, measured at
         // 4K x 256 6.24 ms per iteration against 6.42 with 8 (whose strips re-read 8/7 instead of
@@ -1018,6 +1078,12 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
         h->seg_pixels = rounds * per_round;
         h->grid_x = (g.Wh + h->seg_pixels - 1) / h->seg_pixels;
     }
+    plan_fused2(h);
+    if (h->deep && !h->plan2.ok) {  // no interior for the two-iteration kernel: an ordinary band
+        h->deep = false;
+        set_rows();
+        plan_fused2(h);
+    }
 
 #define CREATE_HIPCHK(call)                                                    \
     do {                                                                       \
@@ -1039,7 +1105,7 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     CREATE_HIPCHK(hipMalloc(&h->cost_lm, (size_t)D * g.Hb * W + 4));
     CREATE_HIPCHK(hipMalloc(&h->cost_px, (size_t)(2 * g.cost_colour_stride)));
     // phi is allocated last, by place_phi(), once the kernels it probes with can run
-    h->part_n = 2ll * h->grid_x * g.Hb;  // one partial per block of the two energy launches
+    h->part_n = 2ll * h->grid_x * (row_end - row_begin);  // one partial per block of the two energy launches
     // + kReduceBlocks entries behind the partials for the first reduction stage's results
     CREATE_HIPCHK(hipMalloc(&h->part_sum, (size_t)(h->part_n + kReduceBlocks) * sizeof(double)));
     CREATE_HIPCHK(hipMalloc(&h->part_max, (size_t)(h->part_n + kReduceBlocks) * sizeof(double)));
@@ -1048,7 +1114,6 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     CREATE_HIPCHK(hipMalloc(&h->d_labels, (size_t)g.Hb * W * sizeof(uint32_t)));
 #undef CREATE_HIPCHK
 
-    plan_fused2(h);
     rc = build_cost(h);
     if (rc == DS_OK) rc = place_phi(h);
     if (rc == DS_OK) rc = init_phi(h);
@@ -1193,8 +1258,10 @@ int ds_get_cost(ds_handle *h, uint8_t *out)
     if (!out) return fail(h, DS_ERR_ARG, "out is NULL");
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
-    const size_t bytes = (size_t)h->g.D * h->g.Hb * h->g.W;
-    HIPCHK(h, hipMemcpyAsync(out, h->cost_lm, bytes, hipMemcpyDeviceToHost, h->stream));
+    // [D][stored rows][W] on the device, the band's own rows of every label to the host
+    const size_t own_bytes = (size_t)(own_end(h) - own_begin(h)) * h->g.W, stored_bytes = (size_t)h->g.Hb * h->g.W;
+    HIPCHK(h, hipMemcpy2DAsync(out, own_bytes, h->cost_lm + (size_t)h->ext_up * h->g.W, stored_bytes, own_bytes,
+                               (size_t)h->g.D, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DS_OK;
 }
@@ -1205,7 +1272,8 @@ int ds_sweep(ds_handle *h, int colour, int row_begin, int row_end)
     if (colour != 0 && colour != 1) return fail(h, DS_ERR_ARG, "colour must be 0 or 1");
     if (row_begin < h->g.row0 || row_end > h->g.row0 + h->g.Hb || row_begin > row_end)
         return fail(h, DS_ERR_ARG, "rows outside the handle's band");
-    int rc = use_device(h);
+    int rc = not_deep(h, "ds_sweep");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     return launch_sweep(h, colour, row_begin, row_end);
 }
@@ -1220,7 +1288,8 @@ int ds_sweep_pair(ds_handle *h, int colour, int next, int row_begin, int row_end
     if (row_begin < lo || row_end > hi || row_begin > row_end || row_begin2 < lo || row_end2 > hi ||
         row_begin2 > row_end2 || (row_begin2 < row_end && row_begin < row_end2 && row_begin < row_end && row_begin2 < row_end2))
         return fail(h, DS_ERR_ARG, "row ranges must lie inside the handle's band and not overlap");
-    int rc = use_device(h);
+    int rc = not_deep(h, "ds_sweep_pair");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     if (!next) return launch_sweep(h, colour, row_begin, row_end, nullptr, row_begin2, row_end2);
     ds::Geometry upcoming = h->g;
@@ -1231,8 +1300,8 @@ int ds_sweep_pair(ds_handle *h, int colour, int next, int row_begin, int row_end
 int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end)
 {
     if (!h || !row_begin || !row_end) return DS_ERR_ARG;
-    *row_begin = *row_end = h->g.row0;
-    if (h->fused_waves) fused_safe_rows(h, row_begin, row_end);
+    *row_begin = *row_end = own_begin(h);
+    if (h->fused_waves && !h->deep) fused_safe_rows(h, row_begin, row_end);
     if (*row_end < *row_begin) *row_end = *row_begin;
     return DS_OK;
 }
@@ -1242,7 +1311,8 @@ int ds_iterate_rows(ds_handle *h, int row_begin, int row_end)
     if (!h) return DS_ERR_ARG;
     if (!h->fused_waves) return fail(h, DS_ERR_STATE, "the fused iteration kernel is switched off on this handle (DS_FUSED=off)");
     if (row_begin >= row_end) return fail(h, DS_ERR_ARG, "ds_iterate_rows needs at least one row");
-    int rc = use_device(h);
+    int rc = not_deep(h, "ds_iterate_rows");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     return launch_fused(h, row_begin, row_end);
 }
@@ -1253,7 +1323,8 @@ int ds_sweep_next(ds_handle *h, int row_begin, int row_end)
     if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no second set of colour-1 planes");
     if (row_begin < h->g.row0 || row_end > h->g.row0 + h->g.Hb || row_begin > row_end)
         return fail(h, DS_ERR_ARG, "rows outside the handle's band");
-    int rc = use_device(h);
+    int rc = not_deep(h, "ds_sweep_next");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     ds::Geometry next = h->g;
     for (int s = 0; s < 4; ++s) next.plane_off[1][s] = h->alt_off[s];
@@ -1264,7 +1335,8 @@ int ds_finish_iterations(ds_handle *h)
 {
     if (!h) return DS_ERR_ARG;
     if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no fused iteration kernel");
-    int rc = use_device(h);
+    int rc = not_deep(h, "ds_finish_iterations");
+    if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
     return materialise_first_colour(h, h->g.row0, h->g.row0 + h->g.Hb);
 }
@@ -1381,13 +1453,14 @@ int ds_iterate_raster(ds_handle *h, int n_iters)
 static int launch_energy(ds_handle *h, double *part_sum, double *part_max, double *block_sum, double *block_max,
                          double *result)
 {
-    const dim3 grid(h->grid_x, h->g.Hb), block(ds::kBlock);
+    const ds::Geometry own = own_view(h);
+    const dim3 grid(h->grid_x, own.Hb), block(ds::kBlock);
     const long long half = h->part_n / 2;
     for (int colour = 0; colour < 2; ++colour) {
         int rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
             hipLaunchKernelGGL((ds::energy_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream,
-                               h->g, static_cast<const T *>(h->phi), h->cost_px, (T)h->lambda, colour,
+                               own, static_cast<const T *>(h->phi), own_cost(h), (T)h->lambda, colour,
                                h->seg_pixels, part_sum + colour * half, part_max + colour * half);
             return DS_OK;
         });
@@ -1457,19 +1530,20 @@ int ds_labels(ds_handle *h, int mode, uint32_t *out)
     int rc = need_current(h, "ds_labels");
     if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
-    const dim3 grid(h->grid_x, h->g.Hb), block(ds::kBlock);
+    const ds::Geometry own = own_view(h);
+    const dim3 grid(h->grid_x, own.Hb), block(ds::kBlock);
     for (int colour = 0; colour < 2; ++colour) {
         rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
             hipLaunchKernelGGL((ds::labels_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream,
-                               h->g, static_cast<const T *>(h->phi), h->cost_px, (T)h->lambda, colour,
+                               own, static_cast<const T *>(h->phi), own_cost(h), (T)h->lambda, colour,
                                h->seg_pixels, mode, h->d_labels);
             return DS_OK;
         });
         if (rc != DS_OK) return rc;
         HIPCHK(h, hipGetLastError());
     }
-    HIPCHK(h, hipMemcpyAsync(out, h->d_labels, (size_t)h->g.Hb * h->g.W * sizeof(uint32_t),
+    HIPCHK(h, hipMemcpyAsync(out, h->d_labels, (size_t)own.Hb * own.W * sizeof(uint32_t),
                              hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DS_OK;
@@ -1488,13 +1562,13 @@ int ds_set_phi_rows(ds_handle *h, int row_begin, int row_end, const void *in)
 int ds_get_phi(ds_handle *h, void *out)
 {
     if (!h) return DS_ERR_ARG;
-    return phi_rows(h, h->g.row0, h->g.row0 + h->g.Hb, out, nullptr);
+    return phi_rows(h, own_begin(h), own_end(h), out, nullptr);
 }
 
 int ds_set_phi(ds_handle *h, const void *in)
 {
     if (!h) return DS_ERR_ARG;
-    return phi_rows(h, h->g.row0, h->g.row0 + h->g.Hb, nullptr, in);
+    return phi_rows(h, own_begin(h), own_end(h), nullptr, in);
 }
 
 int ds_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_t *bytes)
@@ -1502,6 +1576,7 @@ int ds_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, size_
     if (!h) return DS_ERR_ARG;
     if ((colour | 1) != 1 || (side | 1) != 1 || (which | 1) != 1 || !dev_ptr || !bytes)
         return fail(h, DS_ERR_ARG, "bad ds_halo argument");
+    if (not_deep(h, "ds_halo") != DS_OK) return DS_ERR_STATE;
     const ds::Geometry &g = h->g;
     // top: send slot 1 of band row 1, receive slot 3 into halo row 0;
     // bottom: send slot 3 of band row Hb, receive slot 1 into halo row Hb + 1.
@@ -1518,6 +1593,7 @@ int ds_halo_next(ds_handle *h, int side, int which, void **dev_ptr, size_t *byte
     if (!h) return DS_ERR_ARG;
     if ((side | 1) != 1 || (which | 1) != 1 || !dev_ptr || !bytes) return fail(h, DS_ERR_ARG, "bad ds_halo_next argument");
     if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no second set of colour-1 planes");
+    if (not_deep(h, "ds_halo_next") != DS_OK) return DS_ERR_STATE;
     const ds::Geometry &g = h->g;
     const int slot = side == 0 ? (which == 0 ? 1 : 3) : (which == 0 ? 3 : 1);
     const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
@@ -1633,8 +1709,8 @@ int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_beg
     if (W) *W = h->g.W;
     if (D) *D = h->g.D;
     if (dtype) *dtype = h->dtype;
-    if (row_begin) *row_begin = h->g.row0;
-    if (row_end) *row_end = h->g.row0 + h->g.Hb;
+    if (row_begin) *row_begin = own_begin(h);
+    if (row_end) *row_end = own_end(h);
     return DS_OK;
 }
 
@@ -1642,7 +1718,7 @@ int ds_co_begin(ds_handle *h, double epsilon)
 {
     if (!h) return DS_ERR_ARG;
     if (!(epsilon >= 0.0)) return fail(h, DS_ERR_ARG, "epsilon must be >= 0");
-    const ds::Geometry &g = h->g;
+    const ds::Geometry g = own_view(h);
     if (h->dtype == DS_F32) {
         // Vertices and edges are compared in the handle's precision.  An epsilon below the spacing of
         // f32 numbers at the size the potentials reach (costs up to 255 plus lambda * (D - 1)) cannot
@@ -1697,7 +1773,7 @@ int ds_co_begin(ds_handle *h, double epsilon)
         rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
             hipLaunchKernelGGL((ds::co_init_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
-                               static_cast<const T *>(h->phi), h->cost_px, (T)h->lambda, (T)epsilon, colour,
+                               static_cast<const T *>(h->phi), own_cost(h), (T)h->lambda, (T)epsilon, colour,
                                h->seg_pixels, h->co_alive, static_cast<T *>(h->co_gmin));
             return DS_OK;
         });
@@ -1714,7 +1790,7 @@ int ds_co_begin(ds_handle *h, double epsilon)
 // out to whole blocks).
 static int co_launch_pass(ds_handle *h, int radius = -1, int wi = 0, int wj = 0)
 {
-    const ds::Geometry &g = h->g;
+    const ds::Geometry g = own_view(h);
     int row_first = g.row0, rows = g.Hb, seg_first = 0, segs = h->grid_x, col_lo = 0, col_hi = g.W - 1;
     if (radius >= 0) {
         const int r0 = wi - radius > g.row0 ? wi - radius : g.row0;
@@ -1767,7 +1843,7 @@ int ds_co_halo(ds_handle *h, int colour, int side, int which, void **dev_ptr, si
     if ((colour | 1) != 1 || (side | 1) != 1 || (which | 1) != 1 || !dev_ptr || !bytes)
         return fail(h, DS_ERR_ARG, "bad ds_co_halo argument");
     if (!h->co_begun) return fail(h, DS_ERR_STATE, "ds_co_halo before ds_co_begin");
-    const ds::Geometry &g = h->g;
+    const ds::Geometry g = own_view(h);
     // rows of the mask buffer: 0 = halo above, 1..Hb = the band, Hb + 1 = halo below
     const int il = side == 0 ? (which == 0 ? 1 : 0) : (which == 0 ? g.Hb : g.Hb + 1);
     *dev_ptr = h->co_alive + colour * ds::mask_colour_stride(g) + (long long)il * g.Wh * g.Dpad;
@@ -1779,7 +1855,7 @@ int ds_co_finish(ds_handle *h, int empty, uint32_t *labels, uint8_t *alive_out, 
 {
     if (!h) return DS_ERR_ARG;
     if (!h->co_begun) return fail(h, DS_ERR_STATE, "ds_co_finish before ds_co_begin");
-    const ds::Geometry &g = h->g;
+    const ds::Geometry g = own_view(h);
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
     if (alive_out && !h->co_host_order) {
@@ -2108,12 +2184,13 @@ int ds_checksum(ds_handle *h, uint64_t *out)
     HIPCHK(h, hipMemsetAsync(h->d_checksum, 0, sizeof(unsigned long long), h->stream));
     long long blocks = (8 * h->plane_elems + ds::kBlock - 1) / ds::kBlock;
     if (blocks > 16384) blocks = 16384;
+    const ds::Geometry own = own_view(h);
     if (h->dtype == DS_F64)
         hipLaunchKernelGGL(ds::checksum_kernel<double>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
-                           h->stream, h->g, static_cast<const double *>(h->phi), h->d_checksum);
+                           h->stream, own, static_cast<const double *>(h->phi), h->d_checksum);
     else
         hipLaunchKernelGGL(ds::checksum_kernel<float>, dim3((unsigned)blocks), dim3(ds::kBlock), 0,
-                           h->stream, h->g, static_cast<const float *>(h->phi), h->d_checksum);
+                           h->stream, own, static_cast<const float *>(h->phi), h->d_checksum);
     HIPCHK(h, hipGetLastError());
     unsigned long long v = 0;
     HIPCHK(h, hipMemcpyAsync(&v, h->d_checksum, sizeof v, hipMemcpyDeviceToHost, h->stream));

@@ -30,10 +30,12 @@ def _free_port():
     return port
 
 
-def _gloo_worker(rank, world, port, dtype, D, H, W, out):
+def _gloo_worker(rank, world, port, dtype, D, H, W, out, halo="one-row"):
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(240, exit=True, file=sys.stderr)  # a stuck rank ends itself
+    if halo == "deep":
+        os.environ["DS_BAND_HALO"] = "deep"
     import torch
     import torch.distributed as dist
     load_package()
@@ -71,7 +73,8 @@ def _gloo_worker(rank, world, port, dtype, D, H, W, out):
                 and np.array_equal(got["labels"], want["labels"][rb:re]) and got["not_empty"] == want["not_empty"]
         if not (same and e_ok and co_ok):
             print("rank", rank, "phi same:", same, "energy", energy, "ref", e_ref, "crossing-out", co_ok, flush=True)
-        out[rank] = (bool(same), bool(e_ok), bool(co_ok), steps)
+        labels_ok = np.array_equal(g.labels(0), whole.labels(0)[rb:re]) and np.array_equal(g.get_cost(), whole.get_cost()[:, rb:re])
+        out[rank] = (bool(same), bool(e_ok), bool(co_ok and labels_ok), steps)
         g.close()
         whole.close()
     finally:
@@ -105,6 +108,58 @@ def test_ranks_sharing_one_gpu(world, dtype, D, H, W):
         assert steps == [0] * world, steps
     # the narrow f32 cases with D = 64 / 256: whichever bands have eight interior rows and room for
     # one strip step by two beside neighbours that do not (29 x 75 x 256: the 15-row band only)
+
+
+@pytest.mark.parametrize("world,D,H,W", [(3, 64, 60, 330), (2, 128, 41, 420), (2, 256, 36, 330), (3, 64, 50, 330),
+                                         (2, 40, 40, 500), (4, 256, 70, 330)])
+def test_deep_halo_bands(world, D, H, W):
+    """DS_BAND_HALO=deep: bands of 16 rows or more keep four rows of each neighbour and exchange once
+    per two-iteration step.  Same bar: every band's potentials, energy, labels, cost and crossing-out
+    masks equal to the unpartitioned image's; every band has stepped by two (1 + 0 + 0 + 3 steps)."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gloo_worker, args=(world, _free_port(), "f32", D, H, W, out, "deep"), nprocs=world, join=True)
+    for rank in range(world):
+        assert out[rank][:3] == (True, True, True), "rank %d: %s" % (rank, out[rank])
+        assert out[rank][3] == 4, "rank %d ran %d two-iteration steps" % (rank, out[rank][3])
+
+
+def _mixed_worker(rank, world, port, out):
+    """Rank 0 asks for the deep halo, rank 1 does not: attaching must fail on both, not hang."""
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(120, exit=True, file=sys.stderr)
+    if rank == 0:
+        os.environ["DS_BAND_HALO"] = "deep"
+    import torch
+    import torch.distributed as dist
+    load_package()
+    from stereo_vision_amd import bands, diffstereo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        left, right = random_pair(40, 400, seed=8)
+        rb, re = bands.partition_rows(40, world)[rank]
+        g = diffstereo.DiffusionGraph(left, right, 64, 1.2, dtype="f32", row_begin=rb, row_end=re, device=0)
+        try:
+            bands.Bands(g, bands.GlooTransport(), rank, world)
+            out[rank] = "attached"
+        except diffstereo.DiffStereoError as exc:
+            out[rank] = "refused" if exc.code == -3 and "DS_BAND_HALO" in str(exc) else repr(exc)
+        g.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bands_must_agree_on_the_halo_depth():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_mixed_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == "refused" and out[1] == "refused", dict(out)
 
 
 def _rccl_worker(rank, dtype, D, rows, W, out):
@@ -142,7 +197,11 @@ def _rccl_worker(rank, dtype, D, rows, W, out):
     same = (np.array_equal(pa[1:-1], pb[1:-1]) and np.array_equal(pa[0, :, 3], pb[0, :, 3])
             and np.array_equal(pa[-1, :, 1], pb[-1, :, 1]))
     moved = not np.array_equal(pa[0], phi0[rb - 1].astype(pa.dtype))
-    stepped = a.fused2_info()["steps"] == (2 if W >= 330 else 0)
+    # bands of 14 rows or more with an interior for the two-iteration kernel (f32, D a multiple of 4,
+    # wide enough for a strip) step by two
+    by_two = a.fused2_info()["available"] and re - rb >= 14
+    assert by_two == ((W >= 330 or D == 200) and dtype == "f32" and re - rb >= 14), (by_two, dtype, D, rows, W)
+    stepped = a.fused2_info()["steps"] == (iters // 2 if by_two else 0)
     out[0] = (bool(same), bool(moved), a.checksum() == b.checksum(), e_a == b.energy() and stepped)
     a.close()
     b.close()
@@ -163,12 +222,14 @@ def test_rccl_self_exchange_matches_device_copies(dtype, D, rows, W):
     assert out[0] == (True, True, True, True), out[0]
 
 
-def _wide_worker(rank, world, port, out):
+def _wide_worker(rank, world, port, out, halo="one-row"):
     """One of four bands of 270 rows of a 3840-wide image with 256 disparities, f32: the band
     geometry of the 4K benchmark on eight GPUs (its widths, its strips, its unequal row segments)."""
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(280, exit=True, file=sys.stderr)
+    if halo == "deep":
+        os.environ["DS_BAND_HALO"] = "deep"
     import torch
     import torch.distributed as dist
     load_package()
@@ -202,15 +263,17 @@ def _wide_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_bands_of_the_4k_benchmark_geometry():
+@pytest.mark.parametrize("halo", ["one-row", "deep"])
+def test_bands_of_the_4k_benchmark_geometry(halo):
     """3840 x 1080 x 256, f32, four ranks sharing the GPU, seven iterations through ds_band_iterate
     against ds_iterate on the whole image: every band's first and last six rows bit for bit, the
-    bands' checksums adding up to the image's (so every other row agrees too), the energy."""
+    bands' checksums adding up to the image's (so every other row agrees too), the energy.  Once
+    with one halo row and four exchanges per two-iteration step, once with the deep halo and one."""
     import torch.multiprocessing as mp
     world = 4
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_wide_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_wide_worker, args=(world, _free_port(), out, halo), nprocs=world, join=True)
     for rank in range(world):
         assert out[rank][:2] == (True, True), "rank %d: %s" % (rank, out[rank])
         assert out[rank][2] == 3, "rank %d ran %d two-iteration steps" % (rank, out[rank][2])

@@ -1,5 +1,7 @@
-"""Two iterations per launch (ds_iterate on whole-image f32 handles with D = 64 / 128 / 256)
-against one iteration per launch (DS_FUSED2=off) and the O(D) oracle.  Needs a GPU.
+"""Two iterations per launch (ds_iterate on whole-image f32 handles whose D is a multiple of 4:
+D = 64 / 128 / 256 fill the lanes of a pixel slot, other multiples of 4 take the kernel's
+instantiation for partly filled slots) against one iteration per launch (DS_FUSED2=off) and the
+O(D) oracle.  Needs a GPU.
 
 Bar: bit-identical phi (integer-exact comparison of the float bit patterns via array_equal),
 identical labels, equal energy."""
@@ -17,7 +19,9 @@ from stereo_vision_amd import diffstereo, synth  # noqa: E402
 
 # (H, W, D): interiors of a few strips and a few rows; odd widths; rows whose count is odd
 SHAPES = [(20, 400, 256), (21, 333, 256), (30, 700, 128), (17, 421, 128), (24, 600, 64), (17, 390, 64),
-          (45, 330, 256)]
+          (45, 330, 256),
+          # D below the lanes' capacity: the reference's own 40, and 100 / 200 / 8 / 132 / 60
+          (24, 600, 40), (19, 333, 100), (22, 500, 200), (17, 400, 8), (20, 421, 132), (31, 390, 60)]
 
 
 @pytest.mark.parametrize("H,W,D", SHAPES)
@@ -53,7 +57,8 @@ def test_pairs_of_iterations_equal_single_iterations(monkeypatch, H, W, D):
 
 
 def test_handles_without_an_interior_fall_back():
-    for H, W, D, dtype in ((20, 52, 40, "f32"), (11, 400, 256, "f32"), (20, 400, 200, "f32"), (20, 400, 256, "f64")):
+    for H, W, D, dtype in ((20, 52, 40, "f32"), (11, 400, 256, "f32"), (20, 400, 202, "f32"), (20, 400, 41, "f32"),
+                           (20, 400, 256, "f64")):
         left, right = random_pair(H, W, seed=3)
         g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
         assert not g.fused2_info()["available"], (H, W, D, dtype)
@@ -64,7 +69,7 @@ def test_handles_without_an_interior_fall_back():
         g.close()
     # an image with no column where every label exists: the two-iteration kernel takes it all the
     # same (labels d > j are masked in its strips left of column D)
-    for H, W, D in ((20, 290, 256), (24, 200, 128), (20, 300, 128)):
+    for H, W, D in ((20, 290, 256), (24, 200, 128), (20, 300, 128), (20, 160, 100)):
         left, right = random_pair(H, W, seed=5)
         g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
         info = g.fused2_info()
@@ -105,7 +110,7 @@ def test_full_size_4k_256(monkeypatch):
 
 @pytest.mark.parametrize("dtype,H,W,D", [("f32", 21, 401, 256), ("f32", 19, 333, 128), ("f32", 17, 390, 64),
                                           ("f32", 15, 77, 40), ("f64", 18, 140, 100), ("f64", 13, 300, 256),
-                                          ("f32", 9, 35, 24)])
+                                          ("f32", 9, 35, 24), ("f32", 18, 390, 40), ("f32", 16, 340, 200)])
 def test_last_launch_stores_the_first_colour(monkeypatch, dtype, H, W, D):
     """ds_iterate's last launch writes the first colour's planes itself; with DS_STORE_FIRST=off a
     half-sweep does it afterwards from the planes of the iteration before.  Every plane of both
@@ -155,3 +160,23 @@ def test_any_split_between_the_two_kernels_gives_the_same_bits(monkeypatch, left
     assert np.array_equal(g.get_phi(), ref.get_phi())
     ref.close()
     g.close()
+
+
+def test_partly_filled_slots_can_be_switched_off(monkeypatch):
+    """DS_FUSED2_PARTIAL=off keeps D below the lanes' capacity on one iteration per launch: the
+    same potentials either way."""
+    H, W, D = 20, 500, 40
+    left, right = random_pair(H, W, seed=2)
+    phi0 = random_phi(H, W, D, "f32", seed=3)
+    on = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    monkeypatch.setenv("DS_FUSED2_PARTIAL", "off")
+    off = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f32")
+    monkeypatch.delenv("DS_FUSED2_PARTIAL")
+    assert on.fused2_info()["available"] and not off.fused2_info()["available"]
+    for g in (on, off):
+        g.set_phi(phi0)
+        g.iterate(6)
+    assert on.fused2_info()["steps"] == 3 and off.fused2_info()["steps"] == 0
+    assert np.array_equal(on.get_phi(), off.get_phi())
+    on.close()
+    off.close()
