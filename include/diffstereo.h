@@ -136,6 +136,15 @@ int ds_finish_iterations(ds_handle *h);
  * the fast one).  Synchronous at return.  Whole-image handles only. */
 int ds_iterate_raster(ds_handle *h, int n_iters);
 
+/* The same for a host that calls diffusion_act() one iteration at a time (the reference's
+ * diffusion() does, diffusion_graph.rs:355-365): the call only notes n_iters more iterations and
+ * returns; they are queued as ONE batch -- whose launches carry a diagonal of every iteration in
+ * flight, see ds_iterate_raster -- as soon as anything needs the result: an entry point that
+ * reads or changes phi, or ds_synchronize.  n calls of ds_iterate_raster_async(h, 1) followed by
+ * ds_energy cost what ds_iterate_raster(h, n) costs (H + W - 1 + 2 (n - 1) dependent launches)
+ * instead of n (H + W - 1).  Same bits.  No counterpart in the reference.  Whole-image handles. */
+int ds_iterate_raster_async(ds_handle *h, int n_iters);
+
 /* One colour's half-sweep (diffusion_act_vertexes + diffusion_act_edges,
  * diffusion_graph.rs:302-341, at every pixel of that colour) over the image rows
  * [row_begin, row_end), which must lie inside the handle's band.  Asynchronous:

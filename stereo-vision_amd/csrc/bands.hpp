@@ -347,50 +347,62 @@ int band_fused2_step(ds_handle *h)
 // beyond its own (plus the usual halo row: four rows of the second colour's planes, all four
 // slots), so the two-iteration kernel takes every own row of the band itself -- no half-sweeps
 // of boundary rows, no exchange in the middle of a step -- and the only communication of a step
-// is ONE grouped exchange of those four rows with each neighbour: 4 slots x 4 rows per
-// direction (31.5 MB at 4K x 256 f32) where the one-row protocol moves 4 x 1 row in four
-// dependent exchanges.  The stored rows beyond the own rows are the stored band's frame: the
+// is ONE exchange of those four rows with each neighbour: 4 slots x 4 rows per direction
+// (31.5 MB at 4K x 256 f32), gathered into one buffer so that a neighbour gets one transfer,
+// where the one-row protocol moves 4 x 1 row in four dependent exchanges.  The stored rows beyond the own rows are the stored band's frame: the
 // kernels run over them as over any band and leave stale values there, which the next
 // exchange overwrites with the neighbour's.
 //
 // Order inside a step (o0, o1 = the own rows; X the current planes, Z the ones produced):
-//   handle's stream   the kernel over rows [o0 + 4, o1 - 4): reads own rows of X only, so it
-//                     starts at once -- the exchange of the step before is still in flight
+//   handle's stream   the kernel over rows [o0 + 4, o1 - 4) in two halves: they read own rows of
+//                     X only, so the first half starts at once -- the exchange of the step
+//                     before is still in flight -- and the second when the boundary stream's
+//                     launches of this step are done
 //   frame stream      the column frame (one-iteration kernel, X -> Y -> Z) over the same rows,
 //                     and at the image's top / bottom the rows the two-iteration kernel leaves out
 //   boundary stream   behind the exchange of the step before (stream order): the column frame
 //                     and the two-iteration kernel over rows [o0, o0 + 4) and [o1 - 4, o1), which
-//                     read the halo rows; then an event (all of the step's compute on this
-//                     stream is queued before it); then the exchange of these very rows of Z
-// The handle's stream joins the frame stream and that event, not the exchange, so the next
-// step's long launch and the exchange become runnable at the same moment.  All waits are for
+//                     read the halo rows (after the kernel's launches an event: the second half
+//                     of the long launch waits for it); then an event that closes the step's
+//                     compute on this stream; then the exchange of these very rows of Z
+// The handle's stream never waits for an exchange: the second half starts when the band's first
+// and last rows are done, and at the end of the step it joins the frame stream and the boundary
+// stream's compute.  The exchange has the rest of the step and the next step's first half.  All waits are for
 // work queued earlier; no priorities.
-void *plane_row(const ds_handle *h, long long plane, int image_row)
-{
-    return static_cast<char *>(h->phi) +
-           (size_t)(plane + (long long)(image_row - h->g.row0 + 1) * h->g.row_stride) * h->elem;
-}
-
 int exchange_deep(ds_handle *h, const long long *planes, hipStream_t stream)
 {
-    int peers[8], n = 0;
-    void *send[8], *recv[8];
-    size_t bytes[8];
+    if (h->up < 0 && h->down < 0) return DS_OK;
+    const ds::Geometry &g = h->g;
     const int o0 = own_begin(h), o1 = own_end(h);
+    float *base = static_cast<float *>(h->phi), *stage = static_cast<float *>(h->deep_stage);
+    float *stage_recv = stage + 32 * g.row_stride;
+    // the four rows of every slot's plane into one buffer per neighbour, that buffer in one
+    // transfer, and out again on the other side (rows as rows of the stored planes: halo row = 0)
+    ds::HaloRows out{}, in{};
+    for (int slot = 0; slot < 4; ++slot) out.plane[slot] = in.plane[slot] = planes[slot];
+    out.row[0] = h->up >= 0 ? o0 - g.row0 + 1 : -1;
+    out.row[1] = h->down >= 0 ? o1 - 4 - g.row0 + 1 : -1;
+    in.row[0] = h->up >= 0 ? o0 - 4 - g.row0 + 1 : -1;
+    in.row[1] = h->down >= 0 ? o1 - g.row0 + 1 : -1;
+    const dim3 grid(64, 8), block(ds::kBlock);
+    hipLaunchKernelGGL(ds::halo_rows_kernel<float>, grid, block, 0, stream, base, out, g.row_stride, stage, 1);
+    HIPCHK(h, hipGetLastError());
+    int peers[2], n = 0;
+    void *send[2], *recv[2];
+    size_t bytes[2];
     for (int side = 0; side < 2; ++side) {
         const int peer = side == 0 ? h->up : h->down;
         if (peer < 0) continue;
-        for (int slot = 0; slot < 4; ++slot) {
-            peers[n] = peer;
-            send[n] = plane_row(h, planes[slot], side == 0 ? o0 : o1 - 4);
-            recv[n] = plane_row(h, planes[slot], side == 0 ? o0 - 4 : o1);
-            bytes[n] = (size_t)(4 * h->g.row_stride) * h->elem;
-            ++n;
-        }
+        peers[n] = peer;
+        send[n] = stage + (long long)side * 16 * g.row_stride;
+        recv[n] = stage_recv + (long long)side * 16 * g.row_stride;
+        bytes[n] = (size_t)(16 * g.row_stride) * h->elem;
+        ++n;
     }
-    if (n == 0) return DS_OK;
     if (h->transport.exchange(h->transport.ctx, n, peers, send, recv, bytes, stream) != 0)
         return transport_fail(h, "the deep halo exchange");
+    hipLaunchKernelGGL(ds::halo_rows_kernel<float>, grid, block, 0, stream, base, in, g.row_stride, stage_recv, 0);
+    HIPCHK(h, hipGetLastError());
     return DS_OK;
 }
 
@@ -430,7 +442,14 @@ int band_deep_step(ds_handle *h)
         HIPCHK(h, hipEventRecord(h->ev_rows, h->frame_stream));
         return launch_fused_regions(h, Y, Z, second, n, 1);
     });
-    if (rc == DS_OK) rc = launch_fused2_rows(h, m0, m1);
+    // The long launch in two halves.  The first starts at once; the second waits for the boundary
+    // stream's launches of this step: those read the halo rows, so they come behind the exchange
+    // of the step before and then get compute units only as blocks of the first half end -- if the
+    // whole kernel were queued ahead of them they would trickle through the entire step and this
+    // step's exchange would start when the step is over.  This way the exchange is queued when the
+    // second half starts and has that half and the next step's first half to complete in.
+    const int mid = m0 + (m1 - m0) / 2;
+    if (rc == DS_OK) rc = launch_fused2_rows(h, m0, mid);
     if (rc != DS_OK) return rc;
     // boundary stream: what reads the halo rows, then the exchange of what it made
     rc = on_side_stream(h, [&]() -> int {
@@ -454,16 +473,19 @@ int band_deep_step(ds_handle *h)
         if (r == DS_OK && up) r = launch_fused2_rows(h, o0, m0);
         if (r == DS_OK && down) r = launch_fused2_rows(h, m1, o1);
         if (r != DS_OK) return r;
+        HIPCHK(h, hipEventRecord(h->ev_side, h->side_stream));         // the second half of the long launch waits for this
         HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_rows, 0));  // the second pass reads rows of the frame stream's first
         r = launch_fused_regions(h, Y, Z, second, n, 1);
         if (r != DS_OK) return r;
-        HIPCHK(h, hipEventRecord(h->ev_side, h->side_stream));
+        HIPCHK(h, hipEventRecord(h->ev_halo, h->side_stream));         // all of the step's compute on this stream
         return exchange_deep(h, Z, h->side_stream);
     });
     if (rc != DS_OK) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_side, 0));
-    rc = order_streams(h, h->frame_stream, h->ev_frame, h->stream);
+    rc = launch_fused2_rows(h, mid, m1);
+    if (rc == DS_OK) rc = order_streams(h, h->frame_stream, h->ev_frame, h->stream);
     if (rc != DS_OK) return rc;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_halo, 0));  // the boundary stream's second pass, not the exchange
     for (int s = 0; s < 4; ++s) std::swap(g.plane_off[1][s], h->alt_off[s]);
     h->fused_pending = !h->store_first;
     return DS_OK;

@@ -81,7 +81,7 @@ struct ds_handle {
             int row_begin = 0, row_end = 0, segs = 0;
             int seg_begin[17] = {};  // unequal segments when seg_count > 0
             int seg_count = 0;
-        } cached[4];
+        } cached[6];
         int cached_n = 0;
     } plan2;
     void *phi_y = nullptr;
@@ -106,6 +106,7 @@ struct ds_handle {
     int *co_flags = nullptr;                          // [0] changed, [1] some pixel empty
     long long *co_state = nullptr;                    // co_fix_kernel's report, [2]
     double co_epsilon = 0.0;
+    long long raster_pending = 0;                     // iterations asked for by ds_iterate_raster_async, not yet queued
     bool co_begun = false;
     bool co_fixed = false;                            // the last relaxation pass deleted nothing (or emptied the graph)
     double *eps_buf[2] = {nullptr, nullptr};          // epsilon gaps: values and the sort's second buffer
@@ -118,6 +119,7 @@ struct ds_handle {
     // unchanged; what a caller sees as "the band" is own_view().  Both 0 on every other handle.
     int ext_up = 0, ext_down = 0;
     bool deep = false;
+    void *deep_stage = nullptr;  // [send | recv][up | down][4 slots][4 rows]: one transfer per neighbour and step
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     // set around the last launch(es) of ds_iterate: the fused kernels then store the first colour
@@ -252,9 +254,15 @@ int not_deep(ds_handle *h, const char *who)
     return DS_OK;
 }
 
+int flush_raster(ds_handle *h);
+
 // The readers of phi need both colours' planes current.
 int need_current(ds_handle *h, const char *who)
 {
+    if (h->raster_pending) {
+        const int rc = flush_raster(h);
+        if (rc != DS_OK) return rc;
+    }
     if (h->fused_pending)
         return fail(h, DS_ERR_STATE, std::string(who) + ": the first colour's planes are out of date after "
                                      "ds_iterate_rows; call ds_finish_iterations first");
@@ -274,6 +282,7 @@ void release(ds_handle *h)
     (void)hipFree(h->phi);
     (void)hipFree(h->phi_b);
     (void)hipFree(h->phi_y);
+    (void)hipFree(h->deep_stage);
     (void)hipFree(h->part_sum);
     (void)hipFree(h->part_max);
     (void)hipFree(h->d_scalars);
@@ -702,7 +711,7 @@ int launch_fused2_rows(ds_handle *h, int row_begin, int row_end)
         }
         if (table.n > 0) segs = table.n;
     }
-    if (!cache && p.cached_n < 4) {  // the search above costs milliseconds: once per handle and row range
+    if (!cache && p.cached_n < 6) {  // the search above costs milliseconds: once per handle and row range
         cache = &p.cached[p.cached_n++];
         cache->row_begin = row_begin;
         cache->row_end = row_end;
@@ -1112,6 +1121,7 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     CREATE_HIPCHK(hipMalloc(&h->d_scalars, 2 * sizeof(double)));
     CREATE_HIPCHK(hipMalloc(&h->d_checksum, sizeof(unsigned long long)));
     CREATE_HIPCHK(hipMalloc(&h->d_labels, (size_t)g.Hb * W * sizeof(uint32_t)));
+    if (h->deep) CREATE_HIPCHK(hipMalloc(&h->deep_stage, (size_t)(4 * 16 * g.row_stride) * h->elem));
 #undef CREATE_HIPCHK
 
     rc = build_cost(h);
@@ -1218,6 +1228,10 @@ const char *ds_last_error(const ds_handle *h) { return h ? h->err.c_str() : g_cr
 int ds_set_stream(ds_handle *h, void *hip_stream)
 {
     if (!h) return DS_ERR_ARG;
+    if (h->raster_pending) {
+        const int rc_pending = flush_raster(h);
+        if (rc_pending != DS_OK) return rc_pending;
+    }
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1235,6 +1249,10 @@ int ds_switch_stream(ds_handle *h, void *hip_stream)
 int ds_synchronize(ds_handle *h)
 {
     if (!h) return DS_ERR_ARG;
+    if (h->raster_pending) {
+        const int rc_pending = flush_raster(h);
+        if (rc_pending != DS_OK) return rc_pending;
+    }
     int rc = use_device(h);
     if (rc != DS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1269,6 +1287,10 @@ int ds_get_cost(ds_handle *h, uint8_t *out)
 int ds_sweep(ds_handle *h, int colour, int row_begin, int row_end)
 {
     if (!h) return DS_ERR_ARG;
+    if (h->raster_pending) {
+        const int rc_pending = flush_raster(h);
+        if (rc_pending != DS_OK) return rc_pending;
+    }
     if (colour != 0 && colour != 1) return fail(h, DS_ERR_ARG, "colour must be 0 or 1");
     if (row_begin < h->g.row0 || row_end > h->g.row0 + h->g.Hb || row_begin > row_end)
         return fail(h, DS_ERR_ARG, "rows outside the handle's band");
@@ -1281,6 +1303,10 @@ int ds_sweep(ds_handle *h, int colour, int row_begin, int row_end)
 int ds_sweep_pair(ds_handle *h, int colour, int next, int row_begin, int row_end, int row_begin2, int row_end2)
 {
     if (!h) return DS_ERR_ARG;
+    if (h->raster_pending) {
+        const int rc_pending = flush_raster(h);
+        if (rc_pending != DS_OK) return rc_pending;
+    }
     if (colour != 0 && colour != 1) return fail(h, DS_ERR_ARG, "colour must be 0 or 1");
     if (next && (colour != 1 || !h->fused_waves))
         return fail(h, DS_ERR_ARG, "only the second colour has upcoming planes (and not with DS_FUSED=off)");
@@ -1309,6 +1335,10 @@ int ds_fused_rows(const ds_handle *h, int *row_begin, int *row_end)
 int ds_iterate_rows(ds_handle *h, int row_begin, int row_end)
 {
     if (!h) return DS_ERR_ARG;
+    if (h->raster_pending) {
+        const int rc_pending = flush_raster(h);
+        if (rc_pending != DS_OK) return rc_pending;
+    }
     if (!h->fused_waves) return fail(h, DS_ERR_STATE, "the fused iteration kernel is switched off on this handle (DS_FUSED=off)");
     if (row_begin >= row_end) return fail(h, DS_ERR_ARG, "ds_iterate_rows needs at least one row");
     int rc = not_deep(h, "ds_iterate_rows");
@@ -1320,6 +1350,10 @@ int ds_iterate_rows(ds_handle *h, int row_begin, int row_end)
 int ds_sweep_next(ds_handle *h, int row_begin, int row_end)
 {
     if (!h) return DS_ERR_ARG;
+    if (h->raster_pending) {
+        const int rc_pending = flush_raster(h);
+        if (rc_pending != DS_OK) return rc_pending;
+    }
     if (!h->fused_waves) return fail(h, DS_ERR_STATE, "this handle has no second set of colour-1 planes");
     if (row_begin < h->g.row0 || row_end > h->g.row0 + h->g.Hb || row_begin > row_end)
         return fail(h, DS_ERR_ARG, "rows outside the handle's band");
@@ -1344,6 +1378,10 @@ int ds_finish_iterations(ds_handle *h)
 int ds_iterate(ds_handle *h, int n_iters)
 {
     if (!h) return DS_ERR_ARG;
+    if (h->raster_pending) {
+        const int rc_pending = flush_raster(h);
+        if (rc_pending != DS_OK) return rc_pending;
+    }
     if (n_iters < 0) return fail(h, DS_ERR_ARG, "n_iters must be >= 0");
     if (h->g.row0 != 0 || h->g.Hb != h->g.H)
         return fail(h, DS_ERR_STATE, "ds_iterate needs the whole image; a band must use ds_sweep + halo exchange");
@@ -1424,6 +1462,37 @@ static int launch_raster(ds_handle *h, int n_iters)
     return DS_OK;
 }
 
+// Queues the raster-order iterations that ds_iterate_raster_async has collected, as one batch.
+namespace {
+int flush_raster(ds_handle *h)
+{
+    const long long n = h->raster_pending;
+    h->raster_pending = 0;
+    if (n <= 0) return DS_OK;
+    int rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    for (long long done = 0; done < n && rc == DS_OK;) {
+        const int batch = (int)(n - done < 1000000 ? n - done : 1000000);
+        rc = launch_raster(h, batch);
+        done += batch;
+    }
+    return rc;
+}
+}  // namespace
+
+int ds_iterate_raster_async(ds_handle *h, int n_iters)
+{
+    if (!h) return DS_ERR_ARG;
+    if (n_iters < 0) return fail(h, DS_ERR_ARG, "n_iters must be >= 0");
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_iterate_raster_async needs the whole image");
+    if (h->fused_pending)
+        return fail(h, DS_ERR_STATE, "ds_iterate_raster_async: the first colour's planes are out of date after "
+                                     "ds_iterate_rows; call ds_finish_iterations first");
+    h->raster_pending += n_iters;
+    return DS_OK;
+}
+
 int ds_iterate_raster(ds_handle *h, int n_iters)
 {
     if (!h) return DS_ERR_ARG;
@@ -1431,18 +1500,15 @@ int ds_iterate_raster(ds_handle *h, int n_iters)
     const ds::Geometry &g = h->g;
     if (g.row0 != 0 || g.Hb != g.H)
         return fail(h, DS_ERR_STATE, "ds_iterate_raster needs the whole image");
-    int rc = need_current(h, "ds_iterate_raster");
-    if (rc == DS_OK) rc = use_device(h);
-    if (rc != DS_OK) return rc;
+    if (h->fused_pending) return need_current(h, "ds_iterate_raster");  // the error text; nothing is queued
     // The launches of a step depend on the step before, so the cost is the GPU's kernel-to-kernel
     // turnaround (replaying them from a recorded HIP graph was measured and changes nothing).  With
     // n iterations in one call the steps number H + W - 1 + 2 (n - 1) instead of n (H + W - 1),
     // and each carries up to n diagonals: the longer the call, the closer to the rate the update
-    // itself allows.
-    if (n_iters > 0) {
-        rc = launch_raster(h, n_iters);
-        if (rc != DS_OK) return rc;
-    }
+    // itself allows.  Iterations noted by ds_iterate_raster_async join the batch.
+    h->raster_pending += n_iters;
+    int rc = flush_raster(h);
+    if (rc != DS_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DS_OK;
 }

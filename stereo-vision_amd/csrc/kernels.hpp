@@ -1513,6 +1513,29 @@ __global__ __launch_bounds__(kBlock) void init_phi_kernel(Geometry g, T *__restr
     }
 }
 
+// Deep halo rows (bands.hpp): four consecutive rows of each of four planes to / from one
+// contiguous staging buffer per neighbour, so that a neighbour gets one transfer.  blockIdx.y =
+// 4 * side + slot; rows[side] = first of the four rows as a row of the stored planes (-1: no
+// neighbour on that side); stage + side * 16 rows; pack = 1: planes -> stage, 0: stage -> planes.
+struct HaloRows {
+    long long plane[4];
+    int row[2];
+};
+template <typename T>
+__global__ __launch_bounds__(kBlock) void halo_rows_kernel(T *__restrict__ phi, HaloRows hr, long long row_stride,
+                                                           T *__restrict__ stage, int pack)
+{
+    const int side = blockIdx.y >> 2, slot = blockIdx.y & 3;
+    if (hr.row[side] < 0) return;
+    const long long n4 = row_stride;  // elements of four rows, in vectors of 4
+    T *rows = phi + hr.plane[slot] + (long long)hr.row[side] * row_stride;
+    T *buf = stage + ((long long)side * 16 + slot * 4) * row_stride;
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < n4; k += (long long)gridDim.x * kBlock) {
+        if (pack) store4(buf + 4 * k, load4(rows + 4 * k));
+        else store4(rows + 4 * k, load4(buf + 4 * k));
+    }
+}
+
 // Order-independent checksum: sum over valid (existing slot, d <= j) entries of the
 // band's own rows of the entry's bit pattern (as u64, wrapping).
 template <typename T>

@@ -31,6 +31,7 @@ SYMBOLS = {
     "ds_get_cost": (_I, [_P, _P]),
     "ds_iterate": (_I, [_P, _I]),
     "ds_iterate_raster": (_I, [_P, _I]),
+    "ds_iterate_raster_async": (_I, [_P, _I]),
     "ds_sweep": (_I, [_P, _I, _I, _I]),
     "ds_fused_rows": (_I, [_P, _IP, _IP]),
     "ds_sweep_pair": (_I, [_P, _I, _I, _I, _I, _I, _I]),
@@ -213,6 +214,10 @@ class DiffusionGraph:
     def iterate_raster(self, n_iters):
         """n_iters x diffusion_act in the reference's raster order (anti-diagonal launches)."""
         self._chk(lib().ds_iterate_raster(self._h, int(n_iters)))
+
+    def iterate_raster_async(self, n_iters):
+        """Notes n_iters more raster-order iterations; they run as one batch when the state is needed."""
+        self._chk(lib().ds_iterate_raster_async(self._h, int(n_iters)))
 
     def sweep(self, colour, row_begin=None, row_end=None):
         self._chk(lib().ds_sweep(self._h, int(colour),

@@ -101,3 +101,38 @@ def test_band_refusal():
     with pytest.raises(diffstereo.DiffStereoError):
         band.iterate_raster(1)
     band.close()
+
+
+@pytest.mark.parametrize("dtype,H,W,D", [("f64", 9, 14, 7), ("f32", 12, 40, 64), ("f64", 5, 5, 40)])
+def test_deferred_iterations_equal_one_batch(dtype, H, W, D):
+    """ds_iterate_raster_async only notes the iterations; whatever needs the state next queues them
+    as one batch.  One at a time + a reader, mixed with the red-black entry point and with
+    ds_synchronize: the same bits as ds_iterate_raster."""
+    left, right = random_pair(H, W, seed=H * W)
+    phi0 = random_phi(H, W, D, dtype, seed=13)
+    a = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    b = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    for g in (a, b):
+        g.set_phi(phi0)
+    for _ in range(5):
+        a.iterate_raster_async(1)
+    a.iterate_raster_async(0)
+    b.iterate_raster(5)
+    assert a.energy() == b.energy()                      # a reader: the five run now
+    assert np.array_equal(a.get_phi(), b.get_phi())
+    a.iterate_raster_async(2)
+    a.iterate(1)                                         # a writer: the two run first
+    b.iterate_raster(2)
+    b.iterate(1)
+    assert np.array_equal(a.get_phi(), b.get_phi())
+    a.iterate_raster_async(3)
+    a.synchronize()
+    a.iterate_raster_async(1)
+    a.iterate_raster(1)                                  # the synchronous entry point takes the noted one along
+    b.iterate_raster(5)
+    assert a.checksum() == b.checksum()
+    assert np.array_equal(a.get_phi(), b.get_phi())
+    with pytest.raises(diffstereo.DiffStereoError):
+        a.iterate_raster_async(-1)
+    a.close()
+    b.close()
