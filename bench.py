@@ -48,6 +48,7 @@ WORKLOADS = {
     "4k_256": dict(H=2160, W=3840, D=256, dtype="f32"),
     "4k_256_f64": dict(H=2160, W=3840, D=256, dtype="f64"),  # the reference's own precision: 102 GB of phi
     "1080p_128": dict(H=1080, W=1920, D=128, dtype="f32"),
+    "1080p_40": dict(H=1080, W=1920, D=40, dtype="f32"),     # the reference's own disparity count
     "8k_256_f64": dict(H=4320, W=7680, D=256, dtype="f64"),
     "8k_256_f32": dict(H=4320, W=7680, D=256, dtype="f32"),  # 204 GB of phi: one GPU holds it
 }
@@ -216,7 +217,8 @@ def kernel_account(graph, steps, dtype, D, H, W, workload, world):
         # launch, 4 rows of the second colour read + 4 written (4*sizeof(T), half the pixels are
         # of that colour) + the cost byte of both iterations.
         bytes_per_pl = 4 * elem + 2
-        kernel = "ds::fused2_iteration_kernel<%s, %d, 12, %s>" % (tname, lpp, "false" if D == 4 * lpp else "true")
+        kernel = "ds::fused2_iteration_kernel<%s, %d, %d, %s>" % (tname, lpp, 12 if dtype == "f32" else 8,
+                                                                  "false" if D == 4 * lpp else "true")
         kernel_s, launches, per_launch = ms2 / 1e3, n2, 2
         # valid (pixel, label) pairs of the interior region: column j has min(j, D - 1) + 1 labels.
         # A step covers the region once: in one launch, or (deep-halo bands) in up to three

@@ -570,12 +570,18 @@ void plan_fused2(ds_handle *h)
     if (e && std::strcmp(e, "off") == 0) return;
     // D fills the lanes of a pixel slot (64 / 128 / 256), or fills the lower ones in whole lanes (a
     // multiple of 4: the kernel's PARTIAL instantiation); other D keep one iteration per launch
-    if (h->dtype != DS_F32 || h->fused_waves != 16 || g.D % 4 != 0) return;
+    // f64: 8-wavefront blocks (the registers of a 12-wavefront block do not hold f64 rows), D = 4 LPP
+    // only; 4K x 256: 10.4 ms per iteration against 13.7 for one iteration per launch on the same
+    // device.  DS_FUSED2_F64=off keeps f64 to one iteration per launch.
+    const char *f64 = std::getenv("DS_FUSED2_F64");
+    const bool f64_probe = h->dtype == DS_F64 && !(f64 && std::strcmp(f64, "off") == 0) && h->fused_waves == 8 && g.D == 4 * h->lpp;
+    if (!f64_probe && (h->dtype != DS_F32 || h->fused_waves != 16 || g.D % 4 != 0)) return;
     if (const char *pd = std::getenv("DS_FUSED2_PARTIAL"))  // checking knob: off = only D = 4 LPP
         if (std::strcmp(pd, "off") == 0 && g.D != 4 * h->lpp) return;
-    p.waves = 12;
-    if (const char *w = std::getenv("DS_F2_WAVES")) p.waves = std::atoi(w) == 16 ? 16 : 12;  // tuning knob
-    const int FC1 = 2 * (16 * (64 / h->lpp) - 1);                 // the one-iteration kernel's strip
+    p.waves = f64_probe ? 8 : 12;
+    if (const char *w = std::getenv("DS_F2_WAVES"))  // tuning knob
+        if (!f64_probe) p.waves = std::atoi(w) == 16 ? 16 : 12;
+    const int FC1 = 2 * (h->fused_waves * (64 / h->lpp) - 1);     // the one-iteration kernel's strip
     const int NP = p.waves * (64 / h->lpp), FC2 = 2 * (NP - 3);   // the two-iteration kernel's slots and strip
     // Left edge: two columns short of a multiple of the one-iteration strip, so that the frame's
     // first iteration, which must reach two columns into the interior, still fits whole strips.
@@ -748,6 +754,19 @@ int launch_fused2_rows(ds_handle *h, int row_begin, int row_end)
         if (p.waves == 12) go(lppc, std::integral_constant<int, 12>{});
         else go(lppc, std::integral_constant<int, 16>{});
     };
+    if (h->dtype == DS_F64) {  // the probe: 8 wavefronts
+        double *b64 = static_cast<double *>(h->phi);
+        auto go64 = [&](auto lppc) {
+            hipLaunchKernelGGL((ds::fused2_iteration_kernel<double, decltype(lppc)::value, 8, false>), grid, block, 0, h->stream,
+                               in, b64, b64, np, h->cost_px, h->lambda, p.cL, row_begin, row_end, rows_per_seg, table,
+                               h->store_first ? 1 : 0);
+        };
+        switch (h->lpp) {
+        case 16: go64(std::integral_constant<int, 16>{}); break;
+        case 32: go64(std::integral_constant<int, 32>{}); break;
+        default: go64(std::integral_constant<int, 64>{}); break;
+        }
+    } else
     switch (h->lpp) {
     case 16: with_waves(std::integral_constant<int, 16>{}); break;
     case 32: with_waves(std::integral_constant<int, 32>{}); break;
@@ -785,8 +804,12 @@ bool prepare_fused2(ds_handle *h)
     for (int s = 0; s < 4; ++s) y.plane_off[1][s] = h->y_off[s];
     long long blocks = (8 * h->plane_elems + ds::kBlock - 1) / ds::kBlock;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(ds::init_phi_kernel<float>, dim3((unsigned)blocks), dim3(ds::kBlock), 0, h->stream, y,
-                       static_cast<float *>(h->phi));
+    if (h->dtype == DS_F64)
+        hipLaunchKernelGGL(ds::init_phi_kernel<double>, dim3((unsigned)blocks), dim3(ds::kBlock), 0, h->stream, y,
+                           static_cast<double *>(h->phi));
+    else
+        hipLaunchKernelGGL(ds::init_phi_kernel<float>, dim3((unsigned)blocks), dim3(ds::kBlock), 0, h->stream, y,
+                           static_cast<float *>(h->phi));
     if (hipGetLastError() != hipSuccess) {
         h->plan2.ok = false;
         return false;

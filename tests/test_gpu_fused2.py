@@ -1,7 +1,7 @@
-"""Two iterations per launch (ds_iterate on whole-image f32 handles whose D is a multiple of 4:
-D = 64 / 128 / 256 fill the lanes of a pixel slot, other multiples of 4 take the kernel's
-instantiation for partly filled slots) against one iteration per launch (DS_FUSED2=off) and the
-O(D) oracle.  Needs a GPU.
+"""Two iterations per launch (ds_iterate on f32 handles whose D is a multiple of 4: D = 64 / 128 /
+256 fill the lanes of a pixel slot, other multiples of 4 take the kernel's instantiation for partly
+filled slots; on f64 handles with D = 64 / 128 / 256) against one iteration per launch
+(DS_FUSED2=off) and the O(D) oracle.  Needs a GPU.
 
 Bar: bit-identical phi (integer-exact comparison of the float bit patterns via array_equal),
 identical labels, equal energy."""
@@ -58,7 +58,7 @@ def test_pairs_of_iterations_equal_single_iterations(monkeypatch, H, W, D):
 
 def test_handles_without_an_interior_fall_back():
     for H, W, D, dtype in ((20, 52, 40, "f32"), (11, 400, 256, "f32"), (20, 400, 202, "f32"), (20, 400, 41, "f32"),
-                           (20, 400, 256, "f64")):
+                           (20, 400, 100, "f64"), (20, 400, 40, "f64")):
         left, right = random_pair(H, W, seed=3)
         g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
         assert not g.fused2_info()["available"], (H, W, D, dtype)
@@ -180,3 +180,31 @@ def test_partly_filled_slots_can_be_switched_off(monkeypatch):
     assert np.array_equal(on.get_phi(), off.get_phi())
     on.close()
     off.close()
+
+
+@pytest.mark.parametrize("H,W,D", [(20, 200, 256), (26, 300, 128), (21, 333, 64), (33, 521, 256), (40, 197, 64)])
+def test_f64_pairs_give_the_same_bits(monkeypatch, H, W, D):
+    """The two-iteration kernel in f64 (8-wavefront blocks) against one iteration per launch
+    (DS_FUSED2_F64=off) and the oracle."""
+    left, right = random_pair(H, W, seed=H + D)
+    phi0 = random_phi(H, W, D, "f64", seed=17)
+    monkeypatch.setenv("DS_FUSED2_F64", "off")
+    ref = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f64")
+    monkeypatch.delenv("DS_FUSED2_F64")
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f64")
+    assert g.fused2_info()["available"] and not ref.fused2_info()["available"]
+    f = FastOracle(left, right, D, 1.2, dtype="f64")
+    for x in (ref, g):
+        x.set_phi(phi0)
+    f.potentials[...] = phi0
+    for n in (4, 3, 1, 2):
+        ref.iterate(n)
+        g.iterate(n)
+        f.iterate(n)
+        got = g.get_phi()
+        assert np.array_equal(got, ref.get_phi()), "after a call of %d iterations" % n
+        assert np.array_equal(got, f.potentials)
+    assert g.fused2_info()["steps"] == 2 + 1 + 0 + 1
+    assert g.energy() == ref.energy()
+    ref.close()
+    g.close()
