@@ -49,6 +49,7 @@ WORKLOADS = {
     "4k_256_f64": dict(H=2160, W=3840, D=256, dtype="f64"),  # the reference's own precision: 102 GB of phi
     "1080p_128": dict(H=1080, W=1920, D=128, dtype="f32"),
     "1080p_40": dict(H=1080, W=1920, D=40, dtype="f32"),     # the reference's own disparity count
+    "1080p_40_f64": dict(H=1080, W=1920, D=40, dtype="f64"),  # ... in the reference's own precision
     "8k_256_f64": dict(H=4320, W=7680, D=256, dtype="f64"),
     "8k_256_f32": dict(H=4320, W=7680, D=256, dtype="f32"),  # 204 GB of phi: one GPU holds it
 }

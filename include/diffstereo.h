@@ -247,6 +247,26 @@ int ds_epsilon_gaps_fetch(ds_handle *h, double *out);
  * device).  out needs room for n + 1 values; *n_out = how many were written. */
 int ds_dedup_gaps(const double *sorted, size_t n, double tolerance, int largest_repeated, double *out, size_t *n_out);
 
+/* Replaces epsilon_search(create_array_of_epsilons(graph, 0.0)) (diffusion_stereo/src/
+ * epsilon_search.rs:39-112) for images whose array of gaps cannot exist (H*W*D*(1+4D) values:
+ * 2.2e12 at 3840 x 2160 x 256): the smallest gap epsilon for which the crossing-out leaves a
+ * non-empty graph, or the largest gap if none but it does (the reference's loop never tries its
+ * array's last element).  No array: ds_crossing_out is asked about real numbers until the
+ * interval that holds the answer is a few candidates wide (the predicate only changes at gaps),
+ * then the gaps above the interval's lower end are produced one at a time (ds_epsilon_next)
+ * and tried in ascending order.  Memory: H*W*5 doubles.  With tolerance 0 the reference's array
+ * is the set of distinct gaps, and the result is the reference's up to the rounding of the
+ * predicate described at ds_crossing_out; its tolerance > 0 thins the array out to one value
+ * per run of values within the tolerance, which needs the whole sorted array and is not
+ * reproduced (the result here is then <= the reference's).  f64 whole-image handles only.
+ * stats (optional, 3 values): crossing-outs run, gap passes run, relaxation passes in total. */
+int ds_epsilon_search(ds_handle *h, int max_passes, double *epsilon, long long *stats);
+/* One pass over every gap of create_array_of_epsilons (same values as ds_epsilon_gaps, nothing
+ * stored): *next = the smallest gap that is > lo (+inf if there is none; lo = -1 gives the
+ * smallest gap), *largest = the largest gap, *not_above = how many gaps (of the unsorted,
+ * undeduplicated array) are <= lo.  Any of the three may be NULL.  Whole-image handles. */
+int ds_epsilon_next(ds_handle *h, double lo, double *next, double *largest, unsigned long long *not_above);
+
 /* The same computation in steps, for row bands (one handle per band; the halos of phi must be
  * current, as after ds_sweep + exchange):
  *   ds_co_begin   vertex masks and pair minima of the band's pixels (initialize_with_epsilon);

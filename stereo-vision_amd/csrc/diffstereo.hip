@@ -570,11 +570,11 @@ void plan_fused2(ds_handle *h)
     if (e && std::strcmp(e, "off") == 0) return;
     // D fills the lanes of a pixel slot (64 / 128 / 256), or fills the lower ones in whole lanes (a
     // multiple of 4: the kernel's PARTIAL instantiation); other D keep one iteration per launch
-    // f64: 8-wavefront blocks (the registers of a 12-wavefront block do not hold f64 rows), D = 4 LPP
-    // only; 4K x 256: 10.4 ms per iteration against 13.7 for one iteration per launch on the same
-    // device.  DS_FUSED2_F64=off keeps f64 to one iteration per launch.
+    // f64: 8-wavefront blocks (the registers of a 12-wavefront block do not hold f64 rows); 4K x 256:
+    // 10.4 ms per iteration against 13.7 for one iteration per launch on the same device.
+    // DS_FUSED2_F64=off keeps f64 to one iteration per launch.
     const char *f64 = std::getenv("DS_FUSED2_F64");
-    const bool f64_probe = h->dtype == DS_F64 && !(f64 && std::strcmp(f64, "off") == 0) && h->fused_waves == 8 && g.D == 4 * h->lpp;
+    const bool f64_probe = h->dtype == DS_F64 && !(f64 && std::strcmp(f64, "off") == 0) && h->fused_waves == 8 && g.D % 4 == 0;
     if (!f64_probe && (h->dtype != DS_F32 || h->fused_waves != 16 || g.D % 4 != 0)) return;
     if (const char *pd = std::getenv("DS_FUSED2_PARTIAL"))  // checking knob: off = only D = 4 LPP
         if (std::strcmp(pd, "off") == 0 && g.D != 4 * h->lpp) return;
@@ -757,9 +757,14 @@ int launch_fused2_rows(ds_handle *h, int row_begin, int row_end)
     if (h->dtype == DS_F64) {  // the probe: 8 wavefronts
         double *b64 = static_cast<double *>(h->phi);
         auto go64 = [&](auto lppc) {
-            hipLaunchKernelGGL((ds::fused2_iteration_kernel<double, decltype(lppc)::value, 8, false>), grid, block, 0, h->stream,
-                               in, b64, b64, np, h->cost_px, h->lambda, p.cL, row_begin, row_end, rows_per_seg, table,
-                               h->store_first ? 1 : 0);
+            if (partial)
+                hipLaunchKernelGGL((ds::fused2_iteration_kernel<double, decltype(lppc)::value, 8, true>), grid, block, 0, h->stream,
+                                   in, b64, b64, np, h->cost_px, h->lambda, p.cL, row_begin, row_end, rows_per_seg, table,
+                                   h->store_first ? 1 : 0);
+            else
+                hipLaunchKernelGGL((ds::fused2_iteration_kernel<double, decltype(lppc)::value, 8, false>), grid, block, 0, h->stream,
+                                   in, b64, b64, np, h->cost_px, h->lambda, p.cL, row_begin, row_end, rows_per_seg, table,
+                                   h->store_first ? 1 : 0);
         };
         switch (h->lpp) {
         case 16: go64(std::integral_constant<int, 16>{}); break;
@@ -2204,6 +2209,159 @@ int ds_epsilon_gaps_fetch(ds_handle *h, double *out)
         HIPCHK(h, hipMemcpy(out, h->eps_sorted, h->eps_count * sizeof(double), hipMemcpyDeviceToHost));
     eps_release(h);
     return DS_OK;
+}
+
+// One pass of eps_query_kernel over the whole image.  mins: H * W * 5 doubles (device), result: 3 x u64
+// (device).  out[0] = smallest gap > lo (+inf: none), out[1] = largest gap, out[2] = gaps <= lo.
+static int eps_query(ds_handle *h, double lo, double *mins, int have_mins, unsigned long long *result, double out[3])
+{
+    const ds::Geometry &g = h->g;
+    const unsigned long long init[3] = {0x7ff0000000000000ull, 0ull, 0ull};  // +inf, +0, 0
+    HIPCHK(h, hipMemcpyAsync(result, init, sizeof init, hipMemcpyHostToDevice, h->stream));
+    int shift = 0;
+    while ((1 << shift) < g.D) ++shift;
+    const size_t lds = 9 * (size_t)g.D * sizeof(double);
+    const dim3 grid((unsigned)((size_t)g.H * g.W)), block(ds::kBlock);
+    if (h->dtype == DS_F64)
+        hipLaunchKernelGGL(ds::eps_query_kernel<double>, grid, block, lds, h->stream, g, static_cast<const double *>(h->phi),
+                           h->cost_px, h->lambda, lo, shift, mins, have_mins, result);
+    else
+        hipLaunchKernelGGL(ds::eps_query_kernel<float>, grid, block, lds, h->stream, g, static_cast<const float *>(h->phi),
+                           h->cost_px, h->lambda, lo, shift, mins, have_mins, result);
+    HIPCHK(h, hipGetLastError());
+    unsigned long long host[3] = {0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(host, result, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(&out[0], &host[0], sizeof(double));
+    std::memcpy(&out[1], &host[1], sizeof(double));
+    out[2] = (double)host[2];
+    return DS_OK;
+}
+
+static int eps_query_buffers(ds_handle *h, double **mins, unsigned long long **result)
+{
+    const ds::Geometry &g = h->g;
+    *mins = nullptr;
+    *result = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(mins), (size_t)g.H * g.W * 5 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(result), 3 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        (void)hipFree(*mins);
+        (void)hipFree(*result);
+        (void)hipGetLastError();
+        return fail_hip(h, "hipMalloc (epsilon query)", e);
+    }
+    return DS_OK;
+}
+
+int ds_epsilon_next(ds_handle *h, double lo, double *next, double *largest, unsigned long long *not_above)
+{
+    if (!h) return DS_ERR_ARG;
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_epsilon_next needs the whole image");
+    int rc = need_current(h, "ds_epsilon_next");
+    if (rc == DS_OK) rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    double *mins = nullptr;
+    unsigned long long *result = nullptr;
+    rc = eps_query_buffers(h, &mins, &result);
+    if (rc != DS_OK) return rc;
+    double out[3] = {0., 0., 0.};
+    rc = eps_query(h, lo, mins, 0, result, out);
+    (void)hipFree(mins);
+    (void)hipFree(result);
+    if (rc != DS_OK) return rc;
+    if (next) *next = out[0];
+    if (largest) *largest = out[1];
+    if (not_above) *not_above = (unsigned long long)out[2];
+    return DS_OK;
+}
+
+int ds_epsilon_search(ds_handle *h, int max_passes, double *epsilon, long long *stats)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!epsilon) return fail(h, DS_ERR_ARG, "epsilon is NULL");
+    if (max_passes < 1) return fail(h, DS_ERR_ARG, "max_passes must be >= 1");
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_epsilon_search needs the whole image");
+    if (h->dtype != DS_F64)
+        return fail(h, DS_ERR_ARG, "ds_epsilon_search needs an f64 handle: its candidates go down to 0, which f32 potentials do not resolve");
+    int rc = need_current(h, "ds_epsilon_search");
+    if (rc == DS_OK) rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    double *mins = nullptr;
+    unsigned long long *result = nullptr;
+    rc = eps_query_buffers(h, &mins, &result);
+    if (rc != DS_OK) return rc;
+    long long predicates = 0, queries = 0, passes_total = 0;
+    auto done = [&](int code) {
+        (void)hipFree(mins);
+        (void)hipFree(result);
+        if (stats) {
+            stats[0] = predicates;
+            stats[1] = queries;
+            stats[2] = passes_total;
+        }
+        return code;
+    };
+    // the predicate of epsilon_search.rs:100-102: initialize_with_epsilon, crossing_out, is_not_empty
+    auto consistent = [&](double eps, bool &yes) {
+        int not_empty = 0, passes = 0;
+        const int r = ds_crossing_out(h, eps, max_passes, nullptr, nullptr, &not_empty, &passes);
+        ++predicates;
+        passes_total += passes;
+        yes = not_empty != 0;
+        return r;
+    };
+    double q[3];
+    rc = eps_query(h, -1.0, mins, 0, result, q);  // every gap is > -1: the smallest and the largest candidate
+    ++queries;
+    if (rc != DS_OK) return done(rc);
+    const double smallest = q[0], largest = q[1];
+    // The reference searches the sorted array for the first candidate that leaves a non-empty graph and
+    // never tries the last one (first_index == last_index ends its loop): if no other candidate does,
+    // the largest is the answer.
+    if (!(smallest < largest)) {
+        *epsilon = largest;
+        return done(DS_OK);
+    }
+    bool yes = false;
+    rc = consistent(smallest, yes);
+    if (rc != DS_OK) return done(rc);
+    if (yes) {
+        *epsilon = smallest;
+        return done(DS_OK);
+    }
+    // Invariant: every candidate <= lo fails; the answer is the smallest candidate in (lo, hi] that
+    // passes, or `largest` if none does.  The predicate only changes at candidates, so halving the
+    // interval of real numbers with the predicate narrows it to a few candidates without knowing any.
+    double lo = smallest, hi = largest;
+    for (int it = 0; it < 80; ++it) {
+        const double mid = lo + (hi - lo) * 0.5;
+        if (!(lo < mid && mid < hi)) break;
+        rc = consistent(mid, yes);
+        if (rc != DS_OK) return done(rc);
+        if (yes) hi = mid;
+        else lo = mid;
+    }
+    for (int it = 0; it < 64; ++it) {
+        rc = eps_query(h, lo, mins, 1, result, q);
+        ++queries;
+        if (rc != DS_OK) return done(rc);
+        const double candidate = q[0];
+        if (!(candidate < largest)) {  // nothing between lo and the largest candidate: the untested last element
+            *epsilon = largest;
+            return done(DS_OK);
+        }
+        rc = consistent(candidate, yes);
+        if (rc != DS_OK) return done(rc);
+        if (yes) {
+            *epsilon = candidate;
+            return done(DS_OK);
+        }
+        lo = candidate;
+    }
+    return done(fail(h, DS_ERR_STATE, "ds_epsilon_search: more than 64 candidates inside the last interval of the bisection"));
 }
 
 int ds_dedup_gaps(const double *sorted, size_t n, double tolerance, int largest_repeated, double *out, size_t *n_out)

@@ -142,7 +142,7 @@ struct RowSegments {
     int begin[17];
 };
 
-// PARTIAL (f32 only): D < 4 LPP, D a multiple of 4.  The lanes of a slot beyond its D / 4 label
+// PARTIAL: D < 4 LPP, D a multiple of 4.  The lanes of a slot beyond its D / 4 label
 // lanes load from clamped addresses, store nothing and keep out of the other lanes' minima
 // (messages_lean); everything else is the D = 4 LPP kernel.  A separate instantiation, so that
 // kernel's code does not change.
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
         V M[4];
         const V qc = unpack_cost<T>(cost_word);
         if constexpr (sizeof(T) == 4) messages_lean<LPP, PARTIAL>(psi, lam, lambda, lseg, rev4, M, lane_on);
-        else messages_any<T, LPP>(psi, lam, lambda, lseg, lane, M);
+        else messages<T, LPP, PARTIAL>(psi, lam, lambda, lseg, lane, M, lane_on);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const T avg = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * T(0.25);

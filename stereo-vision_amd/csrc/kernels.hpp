@@ -48,9 +48,13 @@ struct Geometry {
 // ---- the four messages of one pixel --------------------------------------------
 // psi[n] = the neighbour's reverse row (4 labels of this lane; +inf where invalid or
 // where the neighbour does not exist), lam[k] = fl(lambda * d_k), lam1 = lambda.
-template <typename T, int LPP>
+// PARTIAL: the pixel's labels fill only the lower lanes of its segment and lane_on says whether
+// this lane holds labels; a lane that holds none keeps out of the minima of the lanes below it
+// (the suffix minima and the label the lane below takes as its next one), and what it computes
+// for itself is never used.
+template <typename T, int LPP, bool PARTIAL = false>
 __device__ __forceinline__ void messages(const V4<T> psi[4], const T lam[4], T lam1, int lseg, int lane,
-                                         V4<T> M[4])
+                                         V4<T> M[4], bool lane_on = true)
 {
     using R = Real<T>;
     const T inf = R::inf();
@@ -72,7 +76,7 @@ __device__ __forceinline__ void messages(const V4<T> psi[4], const T lam[4], T l
         s[3] = x.v[3] + lam[3];
 #pragma unroll
         for (int k = 2; k >= 0; --k) s[k] = R::min(s[k + 1], x.v[k] + lam[k]);
-        const T xb = excl_suffix_min<T, LPP>(s[0], lseg, lane);
+        const T xb = excl_suffix_min<T, LPP>(PARTIAL ? (lane_on ? s[0] : inf) : s[0], lseg, lane);
 #pragma unroll
         for (int k = 0; k < 4; ++k) bwd[k] = R::min(s[k], xb) - lam[k];
     };
@@ -97,7 +101,7 @@ __device__ __forceinline__ void messages(const V4<T> psi[4], const T lam[4], T l
     // slot 2 (right neighbour): d' <= d+1
     {
         forward(psi[2]);
-        T next = dpp<DPP_WAVE_SHL1>(inf, psi[2].v[0]);
+        T next = dpp<DPP_WAVE_SHL1>(inf, PARTIAL ? (lane_on ? psi[2].v[0] : inf) : psi[2].v[0]);
         if (LPP < 64) next = (lseg == LPP - 1) ? inf : next;
 #pragma unroll
         for (int k = 0; k < 3; ++k) M[2].v[k] = R::min(fwd[k], lam1 + psi[2].v[k + 1]);
@@ -1385,6 +1389,134 @@ __global__ __launch_bounds__(kBlock) void eps_gaps_kernel(Geometry g, const T *_
             const int d = e / D, nd = e % D;
             dst[d * stride + 1 + n * D + nd] = exists(d, nd) ? penalty(d, nd) - emin : inf;
         }
+    }
+}
+
+// ---- epsilon search without the array: one question about the gaps per launch ------------
+// The array of create_array_of_epsilons (epsilon_search.rs:39-74) has H W D (1 + 4 D) entries
+// (2.2e12 at 4K x 256) and exists only to be searched.  This kernel walks the same gaps, in the
+// same f64 expression order as eps_gaps_kernel, and keeps three numbers instead of storing them:
+//   result[0]  the smallest gap that is > lo (as the bits of a non-negative double; +inf if none)
+//   result[1]  the largest gap
+//   result[2]  how many gaps are <= lo
+// Gaps are >= +0 (each is x - min over a set that holds x, in the same arithmetic), and the bit
+// patterns of non-negative doubles order like unsigned integers: one atomicMin / atomicMax /
+// atomicAdd per block.  mins[pixel][5] caches the pixel's vertex minimum and its four pair
+// minima; have_mins = 0 computes and stores them (the first launch for a state of phi), 1 reads them.
+// A block takes one pixel; a thread keeps one neighbour label nd (the low `shift` bits of its index)
+// and walks d in steps of kBlock >> shift; dynamic LDS: 9 D doubles.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void eps_query_kernel(Geometry g, const T *__restrict__ phi,
+                                                           const uint8_t *__restrict__ cost, double lambda, double lo,
+                                                           int shift, double *__restrict__ mins, int have_mins,
+                                                           unsigned long long *__restrict__ result)
+{
+    extern __shared__ double eps_lds[];
+    __shared__ double red[3][kBlock / 64];
+    const int D = g.D;
+    double *own = eps_lds;            // [4][D]
+    double *nbr = own + 4 * D;        // [4][D]: the neighbour's reverse slot
+    double *f = nbr + 4 * D;          // [D]
+    const double inf = __builtin_huge_val();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long pix = blockIdx.x;
+    const int i = (int)(pix / g.W), j = (int)(pix % g.W);
+    const int colour = (i + j) & 1, jc = j >> 1, il = i - g.row0 + 1;
+    const bool has[4] = {j > 0, i > 0, j + 1 < g.W, i + 1 < g.H};
+    const int ni[4] = {i, i - 1, i, i + 1}, nj[4] = {j - 1, j, j + 1, j};
+    const long long own_off = (long long)il * g.row_stride + (long long)jc * g.Dpad;
+
+    for (int e = tid; e < 4 * D; e += kBlock) {
+        const int n = e / D, d = e % D;
+        double a = 0., b = 0.;
+        if (has[n]) {
+            a = (double)phi[g.plane_off[colour][n] + own_off + d];
+            const long long off = (long long)(ni[n] - g.row0 + 1) * g.row_stride + (long long)(nj[n] >> 1) * g.Dpad;
+            b = (double)phi[g.plane_off[1 - colour][n ^ 2] + off + d];
+        }
+        own[e] = a;
+        nbr[e] = b;
+    }
+    __syncthreads();
+    // min / max / sum over the block; every thread gets the result
+    auto block_reduce = [&](double v, int op) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double o = __shfl_xor(v, m);
+            v = op == 0 ? fmin(v, o) : op == 1 ? fmax(v, o) : v + o;
+        }
+        if (lane == 0) red[op][wave] = v;
+        __syncthreads();
+        double r = red[op][0];
+        for (int w = 1; w < kBlock / 64; ++w) r = op == 0 ? fmin(r, red[op][w]) : op == 1 ? fmax(r, red[op][w]) : r + red[op][w];
+        __syncthreads();
+        return r;
+    };
+    double next = inf, largest = 0., count = 0.;  // counts stay far below 2^53
+    auto take = [&](double gap) {
+        if (gap > lo) next = fmin(next, gap);
+        else count += 1.;
+        largest = fmax(largest, gap);
+    };
+    // vertices (diffusion_graph.rs:99-122, 456-470)
+    double vmin = inf;
+    for (int d = tid; d < D; d += kBlock) {
+        double v = inf;
+        if (d <= j) {
+            double sum = 0.;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (has[n]) sum += own[n * D + d];
+            const double q = (double)cost[colour * g.cost_colour_stride + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d];
+            v = q - sum;
+        }
+        f[d] = v;
+        vmin = fmin(vmin, v);
+    }
+    if (have_mins) vmin = mins[pix * 5];
+    else {
+        vmin = block_reduce(vmin, 0);
+        if (tid == 0) mins[pix * 5] = vmin;
+    }
+    __syncthreads();
+    for (int d = tid; d < D; d += kBlock)
+        if (d <= j) take(f[d] - vmin);
+    // edges (diffusion_graph.rs:135-141, 152-169, 480-494)
+    const int nd = tid & ((1 << shift) - 1), dstep = kBlock >> shift;
+    for (int n = 0; n < 4; ++n) {
+        if (!has[n]) continue;  // uniform over the block
+        const bool nd_ok = nd < D && nd <= nj[n];
+        const double psi = nd < D ? nbr[n * D + nd] : 0.;
+        const int dmax = j < D - 1 ? j : D - 1;
+        auto exists = [&](int d) {  // d <= j holds by the loop's limit
+            if (!nd_ok) return false;
+            if (n == 2 && nd > d + 1) return false;
+            if (n == 0 && d > nd + 1) return false;
+            return true;
+        };
+        auto penalty = [&](int d) {
+            const double dist = d > nd ? (double)(d - nd) : (double)(nd - d);
+            return lambda * dist + own[n * D + d] + psi;
+        };
+        double emin;
+        if (have_mins) emin = mins[pix * 5 + 1 + n];
+        else {
+            emin = inf;
+            for (int d = tid >> shift; d <= dmax; d += dstep)
+                if (exists(d)) emin = fmin(emin, penalty(d));
+            emin = block_reduce(emin, 0);
+            if (tid == 0) mins[pix * 5 + 1 + n] = emin;
+        }
+        for (int d = tid >> shift; d <= dmax; d += dstep)
+            if (exists(d)) take(penalty(d) - emin);
+    }
+    next = block_reduce(next, 0);
+    largest = block_reduce(largest, 1);
+    count = block_reduce(count, 2);
+    if (tid == 0) {
+        if (next < inf) atomicMin(result, (unsigned long long)__double_as_longlong(next));
+        atomicMax(result + 1, (unsigned long long)__double_as_longlong(largest));
+        atomicAdd(result + 2, (unsigned long long)count);
     }
 }
 

@@ -47,6 +47,8 @@ SYMBOLS = {
     "ds_epsilon_gaps": (_I, [_P, C.POINTER(C.c_size_t), _IP]),
     "ds_epsilon_gaps_fetch": (_I, [_P, _P]),
     "ds_dedup_gaps": (_I, [_P, C.c_size_t, _D, _I, _P, C.POINTER(C.c_size_t)]),
+    "ds_epsilon_search": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "ds_epsilon_next": (_I, [_P, _D, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
     "ds_co_begin": (_I, [_P, _D]),
     "ds_co_pass": (_I, [_P, _IP, _IP]),
     "ds_co_halo": (_I, [_P, _I, _I, _I, _PP, C.POINTER(C.c_size_t)]),
@@ -302,6 +304,22 @@ class DiffusionGraph:
         self._chk(lib().ds_dedup_gaps(_ptr(gaps) if len(gaps) else None, len(gaps), float(tolerance),
                                      int(repeated), _ptr(out), C.byref(n)))
         return out[:n.value].copy()
+
+    def epsilon_search(self, max_passes=100000, with_stats=False):
+        """epsilon_search(create_array_of_epsilons(graph, 0.0)) (epsilon_search.rs:39-112) without
+        the array: the smallest gap for which the crossing-out leaves a non-empty graph."""
+        eps = C.c_double()
+        stats = (C.c_longlong * 3)()
+        self._chk(lib().ds_epsilon_search(self._h, int(max_passes), C.byref(eps), stats))
+        if with_stats:
+            return eps.value, {"crossing_outs": stats[0], "gap_passes": stats[1], "relaxation_passes": stats[2]}
+        return eps.value
+
+    def epsilon_next(self, lo):
+        """One pass over all gaps: (smallest gap > lo, largest gap, number of gaps <= lo)."""
+        nxt, largest, count = C.c_double(), C.c_double(), C.c_ulonglong()
+        self._chk(lib().ds_epsilon_next(self._h, float(lo), C.byref(nxt), C.byref(largest), C.byref(count)))
+        return nxt.value, largest.value, count.value
 
     # crossing-out in steps (row bands; see include/diffstereo.h)
     def co_begin(self, epsilon):

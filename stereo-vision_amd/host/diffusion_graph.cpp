@@ -348,6 +348,15 @@ std::vector<double> DiffusionGraph::epsilon_gaps_on_device(bool &largest_repeate
     return gaps;
 }
 
+double DiffusionGraph::epsilon_search_on_device()
+{
+    whole_image_only("this operation");
+    push();
+    double epsilon = 0.;
+    check(ds_epsilon_search(h_, 1 << 30, &epsilon, nullptr));
+    return epsilon;
+}
+
 void DiffusionGraph::build_depth_map(std::size_t iteration)
 {
     pgm_writer(depth_map(), "./images/results/result_" + std::to_string(iteration) + ".pgm", max_disparity);

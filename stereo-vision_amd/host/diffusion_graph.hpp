@@ -87,6 +87,9 @@ public:
     // sorted on the GPU, exact duplicates removed; largest_repeated: the largest one occurred
     // more than once (ds_epsilon_gaps).
     std::vector<double> epsilon_gaps_on_device(bool &largest_repeated);
+    // epsilon_search over the array of all gaps with tolerance 0 (epsilon_search.rs:39-112) without
+    // building the array (ds_epsilon_search): for images of any size.
+    double epsilon_search_on_device();
 
 private:
     DiffusionGraph() = default;

@@ -61,4 +61,10 @@ double epsilon_search(CrossingOutGraph &crossing_out_graph, const std::vector<do
     return array[median];
 }
 
+double epsilon_search_streamed(CrossingOutGraph &crossing_out_graph)
+{
+    if (!crossing_out_graph.on_device()) throw std::invalid_argument("epsilon_search_streamed needs a graph in device mode");
+    return crossing_out_graph.diffusion_graph.epsilon_search_on_device();
+}
+
 }  // namespace stereo

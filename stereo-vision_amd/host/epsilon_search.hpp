@@ -20,4 +20,8 @@ std::vector<double> create_array_of_epsilons(CrossingOutGraph &crossing_out_grap
 // :94-112.  Binary search over `array` (non-empty, sorted ascending).
 double epsilon_search(CrossingOutGraph &crossing_out_graph, const std::vector<double> &array);
 
+// Both steps in one for a graph in device mode, without the array (ds_epsilon_search): what
+// epsilon_search(g, create_array_of_epsilons(g, 0.)) returns, for images of any size.
+double epsilon_search_streamed(CrossingOutGraph &crossing_out_graph);
+
 }  // namespace stereo

@@ -4,7 +4,7 @@
 //
 //   stereovision LEFT.pgm RIGHT.pgm OUT.pgm [--max-disparity N] [--smoothing X]
 //                [--epsilon E] [--batch B] [--max-batches M] [--dtype f64|f32]
-//                [--decode crossing|crossing-host|belief|epsilon-search] [--iterations K]
+//                [--decode crossing|crossing-host|belief|epsilon-search|epsilon-search-streamed] [--iterations K]
 //                [--tolerance T]
 //                [--schedule red-black|raster] [--labeling simple|best] [--quiet]
 //                [--gpus N] [--transport rccl|host] [--share-gpu]
@@ -25,7 +25,8 @@
 // --decode epsilon-search (epsilon_search.rs, disabled in the reference's main) runs
 // --iterations iterations, collects all penalty gaps (small images only; merged within
 // --tolerance), binary-searches the smallest epsilon with a non-empty consistent sub-graph
-// and labels with it.
+// and labels with it.  --decode epsilon-search-streamed is the same search with tolerance 0
+// for images of any size: no array, the gaps are walked on the GPU once per question.
 // --labeling best takes find_best_labeling (the alternative main.rs:64 keeps commented out)
 // instead of simple_best_labeling: one label per pixel fixed in raster order, with a
 // crossing-out after each choice.
@@ -129,7 +130,7 @@ int main(int argc, char **argv)
     std::size_t max_disparity = 40, batch = 200, max_batches = 1000, iterations = 200;
     double smoothing = 1.2, epsilon = -1., tolerance = 1e-9;
     int dtype = DS_F64;
-    bool crossing = true, host_masks = false, verbose = true, raster = false, search = false, best = false;
+    bool crossing = true, host_masks = false, verbose = true, raster = false, search = false, streamed = false, best = false;
     int gpus = 1;
     bool rccl = true, share_gpu = false;
     for (int a = 4; a < argc; ++a) {
@@ -150,13 +151,15 @@ int main(int argc, char **argv)
         else if (o == "--dtype") dtype = std::strcmp(need("--dtype"), "f32") == 0 ? DS_F32 : DS_F64;
         else if (o == "--decode") {
             const std::string mode = need("--decode");
-            if (mode != "crossing" && mode != "crossing-host" && mode != "belief" && mode != "epsilon-search") {
+            if (mode != "crossing" && mode != "crossing-host" && mode != "belief" && mode != "epsilon-search" &&
+                mode != "epsilon-search-streamed") {
                 std::fprintf(stderr, "unknown --decode %s\n", mode.c_str());
                 return 2;
             }
             crossing = mode != "belief";
             host_masks = mode == "crossing-host";
-            search = mode == "epsilon-search";
+            search = mode == "epsilon-search" || mode == "epsilon-search-streamed";
+            streamed = mode == "epsilon-search-streamed";
         }
         else if (o == "--tolerance") tolerance = std::strtod(need("--tolerance"), nullptr);
         else if (o == "--schedule") {
@@ -242,9 +245,14 @@ int main(int argc, char **argv)
         if (search) {
             CrossingOutGraph cog = CrossingOutGraph::initialize(std::move(graph), true);
             cog.diffusion_graph.diffusion(1, iterations, verbose);
-            const std::vector<double> array = create_array_of_epsilons(cog, tolerance);
-            std::printf("Array size: %zu\n", array.size());
-            const double found = epsilon_search(cog, array);
+            double found = 0.;
+            if (streamed) {
+                found = epsilon_search_streamed(cog);
+            } else {
+                const std::vector<double> array = create_array_of_epsilons(cog, tolerance);
+                std::printf("Array size: %zu\n", array.size());
+                found = epsilon_search(cog, array);
+            }
             std::printf("Smallest consistent epsilon: %.17g\n", found);
             if (!cog.consistent_with_epsilon(found)) throw std::runtime_error("no epsilon in the array is consistent");
             disparity_map = best ? cog.find_best_labeling() : cog.simple_best_labeling();

@@ -76,13 +76,15 @@ def diffusion_while_not_consistent(runner, epsilon, batch_size, max_batches=1000
 
 
 def run(left, right, max_disparity=40, smoothing=1.2, epsilon=None, batch=200, max_batches=1000,
-        dtype="f64", log=None, labeling="simple", transport=None):
+        dtype="f64", log=None, labeling="simple", transport=None, device=None):
     """The pipeline on already loaded images.  Uses the default process group if one is
     initialised (one band per rank), else a single band.  Returns (disparity map [H][W] on
     rank 0, None elsewhere; iterations done).  labeling: "simple" = simple_best_labeling
     (crossing_out_graph.rs:318-327, what the reference's main uses), "best" = find_best_labeling
     (:349-364; sequential over the whole image, so one band only).  transport: "rccl" (the
-    library's own) or "gloo" (through host memory); default: by the process group's backend."""
+    library's own) or "gloo" (through host memory); default: by the process group's backend.
+    device: the GPU's index (default: LOCAL_RANK modulo the number of GPUs, 0 in a single process).
+    torch is the control plane only (the process group); its own GPU runtime is never started here."""
     import torch
     import torch.distributed as dist
     from . import bands, diffstereo
@@ -97,11 +99,13 @@ def run(left, right, max_disparity=40, smoothing=1.2, epsilon=None, batch=200, m
         raise ValueError("find_best_labeling walks the whole image pixel by pixel: run it as one process")
     rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
     rb, re = bands.partition_rows(H, world)[rank]
+    if device is None:  # device_count() asks the driver without starting torch's runtime
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1) if multi else 0
     graph = diffstereo.DiffusionGraph(left.astype(np.uint8), right.astype(np.uint8), max_disparity, smoothing,
-                                      dtype=dtype, row_begin=rb, row_end=re, device=torch.cuda.current_device())
+                                      dtype=dtype, row_begin=rb, row_end=re, device=device)
     if transport is None:
         transport = "rccl" if multi and dist.get_backend() == "nccl" else "gloo"
-    link = (bands.RcclComm(rank, world, torch.cuda.current_device()) if multi and transport == "rccl"
+    link = (bands.RcclComm(rank, world, device) if multi and transport == "rccl"
             else bands.GlooTransport())
     runner = bands.Bands(graph, link, rank, world)
     try:
@@ -147,8 +151,6 @@ def main(argv=None):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group("gloo")  # control plane; --backend chooses how halo rows travel
     rank = dist.get_rank() if world > 1 else 0
     try:

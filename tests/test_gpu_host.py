@@ -111,6 +111,19 @@ def test_cli_epsilon_search(tmp_path, golden_dir):
     assert abs(found - want) <= 1e-9 * max(1.0, abs(want))
     m, _, _ = pyoracle.pgm_reader(str(out_pgm))
     assert np.array_equal(m.astype(np.int32), o.simple_best_labeling())
+    # the same search without the array (tolerance 0: every distinct gap is a candidate)
+    want0 = o.epsilon_search(o.create_array_of_epsilons(0.0))
+    o.initialize_with_epsilon(want0)
+    o.crossing_out()
+    run = subprocess.run([os.path.join(HOST, "stereovision"), os.path.join(golden_dir, "left.pgm"),
+                          os.path.join(golden_dir, "right.pgm"), str(out_pgm), "--decode", "epsilon-search-streamed",
+                          "--iterations", "60", "--quiet"],
+                         capture_output=True, text=True, timeout=100, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stdout + run.stderr
+    found = float([ln for ln in run.stdout.splitlines() if ln.startswith("Smallest consistent epsilon")][0].split()[-1])
+    assert abs(found - want0) <= 1e-9 * max(1.0, abs(want0))
+    m, _, _ = pyoracle.pgm_reader(str(out_pgm))
+    assert np.array_equal(m.astype(np.int32), o.simple_best_labeling())
 
 
 def test_cli_find_best_labeling(tmp_path, golden_dir):

@@ -1,0 +1,35 @@
+"""Developer tool: ds_epsilon_search (the reference's epsilon search without its array of gaps) on
+images whose array cannot exist.  env SIZES = "H,W,D;...", ITERS = diffusion iterations before."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from stereo_vision_amd import diffstereo, synth  # noqa: E402
+
+sizes = os.environ.get("SIZES", "400,400,40;1080,1920,128")
+iters = int(os.environ.get("ITERS", "200"))
+for spec in sizes.split(";"):
+    H, W, D = (int(x) for x in spec.split(","))
+    left, right, _ = synth.synthetic_pair(H, W, D)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f64")
+    g.iterate(iters)
+    g.synchronize()
+    t0 = time.perf_counter()
+    nxt, largest, count = g.epsilon_next(-1.0)
+    t_pass = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nxt, largest, count = g.epsilon_next(largest)
+    t_pass2 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eps, stats = g.epsilon_search(with_stats=True)
+    t_search = time.perf_counter() - t0
+    print("%dx%dx%d after %d iterations: %.4g gaps (an array of %.3g GB), largest %.6g; one pass over them %.3f s "
+          "(first, with allocation: %.3f s); search: epsilon = %.17g in %.2f s (%d crossing-outs with %d relaxation "
+          "passes, %d gap passes)" % (W, H, D, iters, count, count * 8 / 1e9, largest, t_pass2, t_pass, eps, t_search,
+                                      stats["crossing_outs"], stats["relaxation_passes"], stats["gap_passes"]), flush=True)
+    g.close()
