@@ -200,6 +200,18 @@ int ds_labels(ds_handle *h, int mode, uint32_t *out);
  * needs an f64 handle from about 50 x 50 pixels on. */
 int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
                     int *not_empty, int *passes);
+/* The same with every comparison made as the reference makes it (crossing_out_graph.rs:78-130):
+ * in f64 whatever the handle's type, each penalty in the reference's expression order from the
+ * side of the pixel that owns the mask entry, thresholds min + epsilon.  The reference keeps two
+ * copies of every edge, one per end, rounded in different orders; its crossing_out (:135-183)
+ * clears a pixel's copy on the death of the neighbour's vertex only through the neighbour's copy,
+ * so a copy whose twin was never set outlives that vertex -- reproduced.  Result: the reference's
+ * vertex masks for ANY epsilon, including one that is itself a gap of the graph (the candidates of
+ * epsilon search), where ds_crossing_out may fall on the other side of a threshold.  Price:
+ * O(D^2) per pixel and pass instead of O(D) (1920 x 1080 x 128: 0.1 s per pass), and H*W*5
+ * doubles.  Whole-image handles.  ds_find_best_labeling may follow. */
+int ds_crossing_out_exact(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
+                          int *not_empty, int *passes);
 
 /* Replaces CrossingOutGraph::find_best_labeling (diffusion_stereo/src/crossing_out_graph.rs:
  * 349-364, with min_vertex_between_existing :284-300 and cross_vertex :336-345) on the masks the
@@ -251,16 +263,19 @@ int ds_dedup_gaps(const double *sorted, size_t n, double tolerance, int largest_
  * epsilon_search.rs:39-112) for images whose array of gaps cannot exist (H*W*D*(1+4D) values:
  * 2.2e12 at 3840 x 2160 x 256): the smallest gap epsilon for which the crossing-out leaves a
  * non-empty graph, or the largest gap if none but it does (the reference's loop never tries its
- * array's last element).  No array: ds_crossing_out is asked about real numbers until the
+ * array's last element).  No array: the crossing-out is asked about real numbers until the
  * interval that holds the answer is a few candidates wide (the predicate only changes at gaps),
  * then the gaps above the interval's lower end are produced one at a time (ds_epsilon_next)
- * and tried in ascending order.  Memory: H*W*5 doubles.  With tolerance 0 the reference's array
- * is the set of distinct gaps, and the result is the reference's up to the rounding of the
- * predicate described at ds_crossing_out; its tolerance > 0 thins the array out to one value
- * per run of values within the tolerance, which needs the whole sorted array and is not
- * reproduced (the result here is then <= the reference's).  f64 whole-image handles only.
+ * and tried in ascending order.  Memory: H*W*5 doubles.
+ * exact = 1: the predicate is ds_crossing_out_exact (the reference's comparisons bit for bit;
+ * f32 handles allowed, their potentials are widened); exact = 0: ds_crossing_out (O(D) per
+ * pixel and pass, the rounding described there; f64 handles only).
+ * With tolerance 0 the reference's array is the set of distinct gaps and the result is the
+ * reference's; its tolerance > 0 thins the array out to one value per run of values within the
+ * tolerance, which needs the whole sorted array and is not reproduced (the result here is then
+ * <= the reference's).  Whole-image handles only.
  * stats (optional, 3 values): crossing-outs run, gap passes run, relaxation passes in total. */
-int ds_epsilon_search(ds_handle *h, int max_passes, double *epsilon, long long *stats);
+int ds_epsilon_search(ds_handle *h, int exact, int max_passes, double *epsilon, long long *stats);
 /* One pass over every gap of create_array_of_epsilons (same values as ds_epsilon_gaps, nothing
  * stored): *next = the smallest gap that is > lo (+inf if there is none; lo = -1 gives the
  * smallest gap), *largest = the largest gap, *not_above = how many gaps (of the unsorted,

@@ -1808,25 +1808,10 @@ int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_beg
     return DS_OK;
 }
 
-int ds_co_begin(ds_handle *h, double epsilon)
+// The crossing-out state of a handle (masks, pair minima, flags), allocated on first use and
+// cleared: all labels dead, the mask's halo rows all alive.
+static int co_state(ds_handle *h, const ds::Geometry &g, double epsilon)
 {
-    if (!h) return DS_ERR_ARG;
-    if (!(epsilon >= 0.0)) return fail(h, DS_ERR_ARG, "epsilon must be >= 0");
-    const ds::Geometry g = own_view(h);
-    if (h->dtype == DS_F32) {
-        // Vertices and edges are compared in the handle's precision.  An epsilon below the spacing of
-        // f32 numbers at the size the potentials reach (costs up to 255 plus lambda * (D - 1)) cannot
-        // be resolved: the masks would hang on rounding noise.  Such a run belongs on an f64 handle.
-        const double reach = 255.0 + std::fabs(h->lambda) * (g.D - 1);
-        const double resolution = reach * 1.1920928955078125e-07;  // 2^-23
-        if (epsilon < resolution)
-            return fail(h, DS_ERR_ARG,
-                        "epsilon " + std::to_string(epsilon) + " is below what f32 potentials resolve here (" +
-                            std::to_string(resolution) + "): use an f64 handle");
-    }
-    int rc = need_current(h, "ds_co_begin");
-    if (rc == DS_OK) rc = use_device(h);
-    if (rc != DS_OK) return rc;
     const size_t mask_bytes = (size_t)(2 * ds::mask_colour_stride(g));
     h->co_begun = false;
     if (!h->co_alive || !h->co_gmin || !h->co_flags) {
@@ -1853,7 +1838,6 @@ int ds_co_begin(ds_handle *h, double epsilon)
     }
     h->co_epsilon = epsilon;
     h->co_fixed = false;
-    const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
     HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
     // Halo rows start all-alive: until the neighbouring band's rows arrive they must not
     // take support away (deletions cannot be undone; a late deletion only costs a pass).
@@ -1863,6 +1847,31 @@ int ds_co_begin(ds_handle *h, double epsilon)
         HIPCHK(h, hipMemsetAsync(base, 1, row_bytes, h->stream));
         HIPCHK(h, hipMemsetAsync(base + (size_t)(g.Hb + 1) * row_bytes, 1, row_bytes, h->stream));
     }
+    return DS_OK;
+}
+
+int ds_co_begin(ds_handle *h, double epsilon)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!(epsilon >= 0.0)) return fail(h, DS_ERR_ARG, "epsilon must be >= 0");
+    const ds::Geometry g = own_view(h);
+    if (h->dtype == DS_F32) {
+        // Vertices and edges are compared in the handle's precision.  An epsilon below the spacing of
+        // f32 numbers at the size the potentials reach (costs up to 255 plus lambda * (D - 1)) cannot
+        // be resolved: the masks would hang on rounding noise.  Such a run belongs on an f64 handle.
+        const double reach = 255.0 + std::fabs(h->lambda) * (g.D - 1);
+        const double resolution = reach * 1.1920928955078125e-07;  // 2^-23
+        if (epsilon < resolution)
+            return fail(h, DS_ERR_ARG,
+                        "epsilon " + std::to_string(epsilon) + " is below what f32 potentials resolve here (" +
+                            std::to_string(resolution) + "): use an f64 handle");
+    }
+    int rc = need_current(h, "ds_co_begin");
+    if (rc == DS_OK) rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    rc = co_state(h, g, epsilon);
+    if (rc != DS_OK) return rc;
+    const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
     for (int colour = 0; colour < 2; ++colour) {
         rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
@@ -2254,6 +2263,88 @@ static int eps_query_buffers(ds_handle *h, double **mins, unsigned long long **r
     return DS_OK;
 }
 
+// ds_crossing_out with the reference's own comparisons (co_exact_kernel); mins: the vertex and pair
+// minima of the current phi (eps_query with have_mins = 0 fills them).
+static int crossing_out_exact(ds_handle *h, double epsilon, const double *mins, int max_passes, uint32_t *labels,
+                              uint8_t *alive_out, int *not_empty, int *passes)
+{
+    const ds::Geometry &g = h->g;
+    int rc = co_state(h, g, epsilon);
+    if (rc != DS_OK) return rc;
+    // the O(D) kernels' pair minima as well, so that every entry point that continues on these
+    // masks (ds_find_best_labeling, ds_co_pass) finds the state it expects
+    const dim3 grid_o(h->grid_x, g.Hb), block(ds::kBlock);
+    for (int colour = 0; colour < 2; ++colour) {
+        rc = dispatch(h, [&](auto t, auto lpp) -> int {
+            using T = decltype(t);
+            hipLaunchKernelGGL((ds::co_init_kernel<T, decltype(lpp)::value>), grid_o, block, 0, h->stream, g,
+                               static_cast<const T *>(h->phi), h->cost_px, (T)h->lambda, (T)epsilon, colour,
+                               h->seg_pixels, h->co_alive, static_cast<T *>(h->co_gmin));
+            return DS_OK;
+        });
+        if (rc != DS_OK) return rc;
+        HIPCHK(h, hipGetLastError());
+    }
+    int shift = 0;
+    while ((1 << shift) < g.D) ++shift;
+    const size_t lds = (size_t)g.D * (8 * sizeof(double) + sizeof(int) + 5) + 8;
+    const dim3 grid((unsigned)((size_t)g.H * g.W));
+    auto launch = [&](int phase) -> int {
+        if (h->dtype == DS_F64)
+            hipLaunchKernelGGL(ds::co_exact_kernel<double>, grid, block, lds, h->stream, g, static_cast<const double *>(h->phi),
+                               h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase);
+        else
+            hipLaunchKernelGGL(ds::co_exact_kernel<float>, grid, block, lds, h->stream, g, static_cast<const float *>(h->phi),
+                               h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase);
+        HIPCHK(h, hipGetLastError());
+        return DS_OK;
+    };
+    rc = launch(0);
+    if (rc != DS_OK) return rc;
+    h->co_begun = true;
+    int done = 0, changed = 1, lost = 0;
+    while (done < max_passes && changed && !lost) {
+        HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
+        rc = launch(1);
+        if (rc != DS_OK) return rc;
+        int host_flags[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        changed = host_flags[0];
+        lost = host_flags[1];
+        ++done;
+    }
+    h->co_fixed = !changed || lost;
+    if (changed && !lost) return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
+    rc = ds_co_finish(h, lost, labels, alive_out, not_empty);
+    if (rc != DS_OK) return rc;
+    if (passes) *passes = done;
+    return DS_OK;
+}
+
+int ds_crossing_out_exact(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
+                          int *not_empty, int *passes)
+{
+    if (!h) return DS_ERR_ARG;
+    if (!(epsilon >= 0.0)) return fail(h, DS_ERR_ARG, "epsilon must be >= 0");
+    if (max_passes < 1) return fail(h, DS_ERR_ARG, "max_passes must be >= 1");
+    const ds::Geometry &g = h->g;
+    if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_crossing_out_exact needs the whole image");
+    int rc = need_current(h, "ds_crossing_out_exact");
+    if (rc == DS_OK) rc = use_device(h);
+    if (rc != DS_OK) return rc;
+    double *mins = nullptr;
+    unsigned long long *result = nullptr;
+    rc = eps_query_buffers(h, &mins, &result);
+    if (rc != DS_OK) return rc;
+    double q[3];
+    rc = eps_query(h, -1.0, mins, 0, result, q);
+    if (rc == DS_OK) rc = crossing_out_exact(h, epsilon, mins, max_passes, labels, alive_out, not_empty, passes);
+    (void)hipFree(mins);
+    (void)hipFree(result);
+    return rc;
+}
+
 int ds_epsilon_next(ds_handle *h, double lo, double *next, double *largest, unsigned long long *not_above)
 {
     if (!h) return DS_ERR_ARG;
@@ -2277,15 +2368,15 @@ int ds_epsilon_next(ds_handle *h, double lo, double *next, double *largest, unsi
     return DS_OK;
 }
 
-int ds_epsilon_search(ds_handle *h, int max_passes, double *epsilon, long long *stats)
+int ds_epsilon_search(ds_handle *h, int exact, int max_passes, double *epsilon, long long *stats)
 {
     if (!h) return DS_ERR_ARG;
     if (!epsilon) return fail(h, DS_ERR_ARG, "epsilon is NULL");
     if (max_passes < 1) return fail(h, DS_ERR_ARG, "max_passes must be >= 1");
     const ds::Geometry &g = h->g;
     if (g.row0 != 0 || g.Hb != g.H) return fail(h, DS_ERR_STATE, "ds_epsilon_search needs the whole image");
-    if (h->dtype != DS_F64)
-        return fail(h, DS_ERR_ARG, "ds_epsilon_search needs an f64 handle: its candidates go down to 0, which f32 potentials do not resolve");
+    if (h->dtype != DS_F64 && !exact)
+        return fail(h, DS_ERR_ARG, "ds_epsilon_search on an f32 handle needs exact = 1: its candidates go down to 0, which comparisons in f32 do not resolve");
     int rc = need_current(h, "ds_epsilon_search");
     if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
@@ -2305,14 +2396,16 @@ int ds_epsilon_search(ds_handle *h, int max_passes, double *epsilon, long long *
         return code;
     };
     // the predicate of epsilon_search.rs:100-102: initialize_with_epsilon, crossing_out, is_not_empty
-    auto consistent = [&](double eps, bool &yes) {
+    auto ask = [&](bool by_reference, double eps, bool &yes) {
         int not_empty = 0, passes = 0;
-        const int r = ds_crossing_out(h, eps, max_passes, nullptr, nullptr, &not_empty, &passes);
+        const int r = by_reference ? crossing_out_exact(h, eps, mins, max_passes, nullptr, nullptr, &not_empty, &passes)
+                                   : ds_crossing_out(h, eps, max_passes, nullptr, nullptr, &not_empty, &passes);
         ++predicates;
         passes_total += passes;
         yes = not_empty != 0;
         return r;
     };
+    auto consistent = [&](double eps, bool &yes) { return ask(exact != 0, eps, yes); };
     double q[3];
     rc = eps_query(h, -1.0, mins, 0, result, q);  // every gap is > -1: the smallest and the largest candidate
     ++queries;
@@ -2336,13 +2429,39 @@ int ds_epsilon_search(ds_handle *h, int max_passes, double *epsilon, long long *
     // passes, or `largest` if none does.  The predicate only changes at candidates, so halving the
     // interval of real numbers with the predicate narrows it to a few candidates without knowing any.
     double lo = smallest, hi = largest;
-    for (int it = 0; it < 80; ++it) {
-        const double mid = lo + (hi - lo) * 0.5;
-        if (!(lo < mid && mid < hi)) break;
-        rc = consistent(mid, yes);
+    auto halve = [&](bool by_reference) -> int {
+        for (int it = 0; it < 80; ++it) {
+            const double mid = lo + (hi - lo) * 0.5;
+            if (!(lo < mid && mid < hi)) break;
+            const int r = ask(by_reference, mid, yes);
+            if (r != DS_OK) return r;
+            if (yes) hi = mid;
+            else lo = mid;
+        }
+        return DS_OK;
+    };
+    // With the reference's comparisons a crossing-out costs O(D^2) per pixel and pass.  The O(D) one
+    // answers the same except within rounding of a gap, so on f64 handles it does the halving and the
+    // reference's comparisons confirm the interval's two ends (and redo the halving on the side that
+    // does not hold: rare, and then only inside an interval that is already small).
+    const bool fast_first = exact && h->dtype == DS_F64;
+    rc = halve(exact && !fast_first);
+    if (rc != DS_OK) return done(rc);
+    if (fast_first) {
+        bool lo_passes = false, hi_passes = true;
+        if (lo > smallest) rc = ask(true, lo, lo_passes);
+        if (rc == DS_OK && hi < largest) rc = ask(true, hi, hi_passes);
         if (rc != DS_OK) return done(rc);
-        if (yes) hi = mid;
-        else lo = mid;
+        if (lo_passes) {
+            hi = lo;
+            lo = smallest;
+            rc = halve(true);
+        } else if (!hi_passes) {
+            lo = hi;
+            hi = largest;
+            rc = halve(true);
+        }
+        if (rc != DS_OK) return done(rc);
     }
     for (int it = 0; it < 64; ++it) {
         rc = eps_query(h, lo, mins, 1, result, q);

@@ -1520,6 +1520,139 @@ __global__ __launch_bounds__(kBlock) void eps_query_kernel(Geometry g, const T *
     }
 }
 
+// ---- crossing-out with the reference's own comparisons -------------------------------------
+// co_init / co_relax decide "is this edge within epsilon of its pair's minimum" from min-plus
+// scans in the handle's precision: right except when a penalty lies within rounding of the
+// threshold -- which is where an epsilon taken from the array of gaps puts one on purpose.
+// This kernel evaluates every comparison as the reference does (crossing_out_graph.rs:78-130), in
+// f64 and its expression order, O(D^2) per pixel and pass:
+//   vertex (t, d):   f_t(d) <= min_d f_t + epsilon                                   (:84-85)
+//   edge, t's copy:  A_t  = (lambda |d - d'| + phi_t(d)) + phi_t'(d') <= min_t,n + epsilon   (:113-115)
+//   edge, t''s copy: A_t' = (lambda |d' - d| + phi_t'(d')) + phi_t(d) <= min_t',n' + epsilon
+// The two copies of one edge are rounded in different orders and may disagree in the last bit.  The
+// reference's crossing_out (:135-183) deletes t's copy when vertex (t', d') is dead only through
+// t''s copy (:150-153 test edges[t'][d'][n'][d] before clearing both), so a copy whose twin was
+// never set survives its neighbour's vertex: (t, d) keeps its support towards n iff some d' has
+//   edge_exists and A_t and (vertex (t', d') alive or not A_t').
+// That condition is monotone in the vertex masks, so in-place passes in any order reach the
+// reference's fixed point.  mins[pixel][5]: vertex minimum and pair minima (eps_query_kernel).
+// phase 0 writes the vertex masks, phase 1 is one relaxation pass.  One block per pixel; a thread
+// keeps one d' (the low `shift` bits of its index) and walks d in steps of kBlock >> shift.
+// Dynamic LDS: 8 D doubles + D ints + 5 D bytes.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *__restrict__ phi,
+                                                          const uint8_t *__restrict__ cost, double lambda, double eps,
+                                                          int shift, const double *__restrict__ mins, uint8_t *alive,
+                                                          int *__restrict__ changed, int phase)
+{
+    extern __shared__ double eps_lds[];
+    const int D = g.D;
+    double *own = eps_lds;            // [4][D]
+    double *nbr = own + 4 * D;        // [4][D]: the neighbour's reverse slot
+    int *support = reinterpret_cast<int *>(nbr + 4 * D);                 // [D]: bit n = an edge towards n holds
+    uint8_t *mine = reinterpret_cast<uint8_t *>(support + D);            // [D]
+    uint8_t *theirs = mine + D;                                          // [4][D]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long pix = blockIdx.x;
+    const int i = (int)(pix / g.W), j = (int)(pix % g.W);
+    const int colour = (i + j) & 1, jc = j >> 1, il = i - g.row0 + 1;
+    const bool has[4] = {j > 0, i > 0, j + 1 < g.W, i + 1 < g.H};
+    const int ni[4] = {i, i - 1, i, i + 1}, nj[4] = {j - 1, j, j + 1, j};
+    const long long own_off = (long long)il * g.row_stride + (long long)jc * g.Dpad;
+    uint8_t *alive_t = mask_base(g, alive, colour) + ((long long)(i - g.row0) * g.Wh + jc) * g.Dpad;
+
+    for (int e = tid; e < 4 * D; e += kBlock) {
+        const int n = e / D, d = e % D;
+        double a = 0., b = 0.;
+        uint8_t m = 0;
+        if (has[n]) {
+            a = (double)phi[g.plane_off[colour][n] + own_off + d];
+            const long long off = (long long)(ni[n] - g.row0 + 1) * g.row_stride + (long long)(nj[n] >> 1) * g.Dpad;
+            b = (double)phi[g.plane_off[1 - colour][n ^ 2] + off + d];
+            if (phase == 1)
+                m = *reinterpret_cast<const volatile uint8_t *>(
+                        mask_base(g, alive, 1 - colour) + ((long long)(ni[n] - g.row0) * g.Wh + (nj[n] >> 1)) * g.Dpad + d) & 1u;
+        }
+        own[e] = a;
+        nbr[e] = b;
+        theirs[e] = m;
+    }
+    __syncthreads();
+    if (phase == 0) {
+        const double limit = mins[pix * 5] + eps;
+        for (int d = tid; d < g.Dpad; d += kBlock) {
+            bool keep = false;
+            if (d < D && d <= j) {
+                double sum = 0.;
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (has[n]) sum += own[n * D + d];
+                const double v = (double)cost[colour * g.cost_colour_stride + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d] - sum;
+                keep = v <= limit;
+            }
+            alive_t[d] = keep ? 1 : 0;
+        }
+        return;
+    }
+    for (int d = tid; d < D; d += kBlock) {
+        mine[d] = *reinterpret_cast<const volatile uint8_t *>(alive_t + d) & 1u;
+        support[d] = 0;
+    }
+    __syncthreads();
+    const int nd = tid & ((1 << shift) - 1), dstep = kBlock >> shift;
+    const int dmax = j < D - 1 ? j : D - 1;
+    const int group_lanes = shift >= 6 ? 64 : (1 << shift);  // lanes of a wavefront that work on the same d
+    const unsigned long long group_mask =
+        group_lanes == 64 ? ~0ull : (((1ull << group_lanes) - 1ull) << (lane & ~(group_lanes - 1)));
+    const bool group_leader = (lane & (group_lanes - 1)) == 0;
+    for (int n = 0; n < 4; ++n) {
+        if (!has[n]) continue;  // uniform over the block
+        const bool nd_ok = nd < D && nd <= nj[n];
+        const double psi = nd < D ? nbr[n * D + nd] : 0.;
+        const bool their_vertex = nd < D && theirs[n * D + nd];
+        const double limit_t = mins[pix * 5 + 1 + n] + eps;
+        const double limit_n = mins[((long long)ni[n] * g.W + nj[n]) * 5 + 1 + (n ^ 2)] + eps;
+        for (int d = tid >> shift; d <= dmax; d += dstep) {
+            if (!mine[d]) continue;  // uniform over the lanes that share d
+            bool ok = nd_ok;
+            if (n == 2 && nd > d + 1) ok = false;
+            if (n == 0 && d > nd + 1) ok = false;
+            if (ok) {
+                const double dist = d > nd ? (double)(d - nd) : (double)(nd - d);
+                const double phi_d = own[n * D + d];
+                const bool a_t = lambda * dist + phi_d + psi <= limit_t;
+                const bool a_n = lambda * dist + psi + phi_d <= limit_n;
+                ok = a_t && (their_vertex || !a_n);
+            }
+            // one LDS atomic per group of lanes that share d, not one per lane
+            const unsigned long long found = __ballot(ok) & group_mask;
+            if (found && group_leader) atomicOr(&support[d], 1 << n);
+        }
+    }
+    __syncthreads();
+    const int need = (has[0] ? 1 : 0) | (has[1] ? 2 : 0) | (has[2] ? 4 : 0) | (has[3] ? 8 : 0);
+    bool died = false, left = false;
+    for (int d = tid; d < D; d += kBlock) {
+        if (!mine[d]) continue;
+        if ((support[d] & need) != need) {
+            alive_t[d] = 0;
+            died = true;
+        } else {
+            left = true;
+        }
+    }
+    died = __any(died);
+    left = __any(left);
+    if (lane == 0 && died) atomicOr(changed, 1);
+    // "the pixel has no vertex left" needs all wavefronts: count those that still hold one
+    __shared__ int holders;
+    if (tid == 0) holders = 0;
+    __syncthreads();
+    if (lane == 0 && left) atomicAdd(&holders, 1);
+    __syncthreads();
+    if (tid == 0 && holders == 0) atomicOr(changed + 1, 1);
+}
+
 // ---- stage 1: cost volume --------------------------------------------------------------
 // cost[d][r][j] = |L[i][j] - R[i][j-d]| for d <= j, else 0; r = band row, i = row0 + r.
 // One thread per 4 consecutive bytes of the label-major volume: lanes run along j, so

@@ -43,11 +43,12 @@ SYMBOLS = {
     "ds_energy_static": (_I, [_P, _P]),
     "ds_labels": (_I, [_P, _I, _P]),
     "ds_crossing_out": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
+    "ds_crossing_out_exact": (_I, [_P, _D, _I, _P, _P, _IP, _IP]),
     "ds_find_best_labeling": (_I, [_P, _I, _P, _IP, C.POINTER(C.c_longlong)]),
     "ds_epsilon_gaps": (_I, [_P, C.POINTER(C.c_size_t), _IP]),
     "ds_epsilon_gaps_fetch": (_I, [_P, _P]),
     "ds_dedup_gaps": (_I, [_P, C.c_size_t, _D, _I, _P, C.POINTER(C.c_size_t)]),
-    "ds_epsilon_search": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "ds_epsilon_search": (_I, [_P, _I, _I, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ds_epsilon_next": (_I, [_P, _D, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
     "ds_co_begin": (_I, [_P, _D]),
     "ds_co_pass": (_I, [_P, _IP, _IP]),
@@ -265,14 +266,16 @@ class DiffusionGraph:
         self._chk(lib().ds_labels(self._h, int(mode), _ptr(out)))
         return out
 
-    def crossing_out(self, epsilon, max_passes=100000, with_mask=False):
+    def crossing_out(self, epsilon, max_passes=100000, with_mask=False, exact=False):
         """initialize_with_epsilon + crossing_out + simple_best_labeling on the GPU
-        (crossing_out_graph.rs:67-183,307-327).  Returns dict(labels, not_empty, passes[, alive])."""
+        (crossing_out_graph.rs:67-183,307-327).  Returns dict(labels, not_empty, passes[, alive]).
+        exact: every comparison as the reference makes it (O(D^2) per pixel and pass)."""
         labels = np.empty((self.rows, self.W), dtype=np.uint32)
         alive = np.empty((self.rows, self.W, self.D), dtype=np.uint8) if with_mask else None
         ne, n = C.c_int(), C.c_int()
-        self._chk(lib().ds_crossing_out(self._h, float(epsilon), int(max_passes), _ptr(labels),
-                                        _ptr(alive) if with_mask else None, C.byref(ne), C.byref(n)))
+        fn = lib().ds_crossing_out_exact if exact else lib().ds_crossing_out
+        self._chk(fn(self._h, float(epsilon), int(max_passes), _ptr(labels),
+                     _ptr(alive) if with_mask else None, C.byref(ne), C.byref(n)))
         out = {"labels": labels, "not_empty": bool(ne.value), "passes": n.value}
         if with_mask:
             out["alive"] = alive
@@ -305,12 +308,13 @@ class DiffusionGraph:
                                      int(repeated), _ptr(out), C.byref(n)))
         return out[:n.value].copy()
 
-    def epsilon_search(self, max_passes=100000, with_stats=False):
+    def epsilon_search(self, exact=True, max_passes=100000, with_stats=False):
         """epsilon_search(create_array_of_epsilons(graph, 0.0)) (epsilon_search.rs:39-112) without
-        the array: the smallest gap for which the crossing-out leaves a non-empty graph."""
+        the array: the smallest gap for which the crossing-out leaves a non-empty graph.
+        exact: the predicate compares as the reference does (crossing_out_exact), else crossing_out."""
         eps = C.c_double()
         stats = (C.c_longlong * 3)()
-        self._chk(lib().ds_epsilon_search(self._h, int(max_passes), C.byref(eps), stats))
+        self._chk(lib().ds_epsilon_search(self._h, int(bool(exact)), int(max_passes), C.byref(eps), stats))
         if with_stats:
             return eps.value, {"crossing_outs": stats[0], "gap_passes": stats[1], "relaxation_passes": stats[2]}
         return eps.value

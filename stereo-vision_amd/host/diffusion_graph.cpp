@@ -353,7 +353,7 @@ double DiffusionGraph::epsilon_search_on_device()
     whole_image_only("this operation");
     push();
     double epsilon = 0.;
-    check(ds_epsilon_search(h_, 1 << 30, &epsilon, nullptr));
+    check(ds_epsilon_search(h_, 1, 1 << 30, &epsilon, nullptr));
     return epsilon;
 }
 

@@ -166,3 +166,54 @@ def test_bands_on_one_gpu_match_whole_image(iters, eps):
         diffstereo.DiffusionGraph(left, right, D, 1.2).co_pass()  # before co_begin
     for b in bands + [whole]:
         b.close()
+
+
+@pytest.mark.parametrize("H,W,D,dtype,iters", [(3, 4, 3, "f64", 0), (2, 5, 6, "f64", 0), (4, 4, 5, "f64", 6), (1, 6, 8, "f64", 0),
+                                               (5, 1, 4, "f64", 3), (3, 7, 12, "f64", 10), (4, 5, 40, "f64", 25),
+                                               (3, 5, 7, "f32", 0), (4, 6, 9, "f32", 8), (2, 3, 70, "f64", 4)])
+def test_exact_comparisons_at_every_gap_of_the_graph(H, W, D, dtype, iters):
+    """ds_crossing_out_exact with epsilon equal to a gap of the graph -- where one comparison of the
+    reference is an equality up to its own rounding -- for (a sample of) every gap: the
+    reference restatement's vertex masks byte for byte.  f32 handles: the reference's f64
+    arithmetic on the widened potentials."""
+    left, right = random_pair(H, W, seed=H + 3 * W + 5 * D)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    if iters == 0:
+        g.set_phi(random_phi(H, W, D, dtype, seed=23))
+    else:
+        g.iterate(iters)
+    phi = np.asarray(g.get_phi(), dtype=np.float64)
+    gaps = g.epsilon_gaps()
+    picks = gaps if len(gaps) <= 150 else gaps[np.unique(np.linspace(0, len(gaps) - 1, 150).astype(int))]
+    o = OracleGraph(left, right, D, 1.2, dtype="f64")
+    o.set_potentials(phi)
+    o.co_alloc(True)
+    differing_fast = 0
+    for eps in picks:
+        o.initialize_with_epsilon(float(eps))
+        o.crossing_out()
+        got = g.crossing_out(float(eps), with_mask=True, exact=True)
+        assert np.array_equal(got["alive"], o.vertices), eps
+        assert got["not_empty"] == o.is_not_empty(), eps
+        if dtype == "f64":
+            differing_fast += int(not np.array_equal(g.crossing_out(float(eps), with_mask=True)["alive"], o.vertices))
+    print("candidates tried: %d, of which the O(D) comparisons decide differently: %d" % (len(picks), differing_fast))
+    g.close()
+
+
+def test_exact_crossing_out_leaves_the_state_other_entry_points_expect():
+    left, right = random_pair(6, 9, seed=4)
+    g = diffstereo.DiffusionGraph(left, right, 5, 1.2, dtype="f64")
+    g.iterate(20)
+    r = g.crossing_out(2.0, with_mask=True, exact=True)
+    fast = g.crossing_out(2.0, with_mask=True)
+    assert np.array_equal(r["alive"], fast["alive"]) and r["not_empty"] == fast["not_empty"]
+    g.crossing_out(2.0, exact=True)
+    best = g.find_best_labeling()
+    g.crossing_out(2.0)
+    assert np.array_equal(best["labels"], g.find_best_labeling()["labels"])
+    band = diffstereo.DiffusionGraph(left, right, 5, 1.2, dtype="f64", row_begin=1, row_end=4)
+    with pytest.raises(diffstereo.DiffStereoError):
+        band.crossing_out(2.0, exact=True)
+    band.close()
+    g.close()

@@ -111,20 +111,32 @@ def test_one_pass_questions_about_the_gaps(H, W, D, dtype):
 
 
 @pytest.mark.parametrize("H,W,D,iters,seed", [(5, 9, 6, 30, 3), (5, 5, 40, 100, 1), (8, 12, 10, 25, 7), (6, 20, 16, 60, 2),
-                                              (12, 9, 7, 5, 4), (9, 14, 33, 40, 5), (3, 3, 2, 0, 6), (7, 11, 12, 0, 8)])
+                                              (12, 9, 7, 5, 4), (9, 14, 33, 40, 5), (3, 3, 2, 0, 6), (7, 11, 12, 0, 8),
+                                              (4, 6, 5, 0, 9), (5, 4, 9, 2, 10), (2, 9, 20, 0, 12)])
 def test_search_without_the_array(H, W, D, iters, seed):
     """ds_epsilon_search against the reference's binary search over the whole array (tolerance 0)
-    with the same predicate, and against the oracle's own search."""
+    with the same predicate, and -- with the reference's own comparisons as predicate -- against the
+    oracle's search."""
     g, o = _graphs(H, W, D, "f64", seed=seed, iters=iters)
     array = g.create_array_of_epsilons(0.0)
     want = _array_search(g, array)
-    got, stats = g.epsilon_search(with_stats=True)
+    got, stats = g.epsilon_search(exact=False, with_stats=True)
     assert got == want, (got, want, stats)
     assert stats["gap_passes"] >= 1 and stats["crossing_outs"] >= 1
     o.co_alloc(True)
-    assert got == o.epsilon_search(o.create_array_of_epsilons(0.0))
+    want_exact = o.epsilon_search(o.create_array_of_epsilons(0.0))
+    got_exact, stats = g.epsilon_search(exact=True, with_stats=True)
+    assert got_exact == want_exact, (got_exact, want_exact, stats)
     # the masks the handle is left with are those of the epsilon found
-    assert g.crossing_out(got)["not_empty"]
+    assert g.crossing_out(got_exact, exact=True)["not_empty"]
+    g.close()
+
+
+def test_search_on_an_f32_handle():
+    """exact = 1 widens the potentials: the oracle's search on the same (widened) potentials."""
+    g, o = _graphs(6, 9, 8, "f32", seed=21, iters=12)
+    o.co_alloc(True)
+    assert g.epsilon_search(exact=True) == o.epsilon_search(o.create_array_of_epsilons(0.0))
     g.close()
 
 
@@ -133,8 +145,10 @@ def test_search_without_the_array_at_a_size_the_array_still_fits():
     the sorted array agree."""
     g, _ = _graphs(48, 64, 40, "f64", seed=11, iters=60)
     array = g.create_array_of_epsilons(0.0)
-    got, stats = g.epsilon_search(with_stats=True)
+    got, stats = g.epsilon_search(exact=False, with_stats=True)
     assert got == _array_search(g, array), stats
+    exact, stats = g.epsilon_search(exact=True, with_stats=True)
+    assert abs(exact - got) <= 1e-9 * max(1.0, got), (exact, got, stats)
     g.close()
 
 
@@ -150,5 +164,5 @@ def test_search_refuses_what_it_cannot_do():
     band.close()
     single = diffstereo.DiffusionGraph(left, right, 4, 1.2, dtype="f32")
     with pytest.raises(diffstereo.DiffStereoError):
-        single.epsilon_search()
+        single.epsilon_search(exact=False)
     single.close()

@@ -26,10 +26,15 @@ for spec in sizes.split(";"):
     nxt, largest, count = g.epsilon_next(largest)
     t_pass2 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    eps, stats = g.epsilon_search(with_stats=True)
+    eps_x, stats_x = g.epsilon_search(exact=True, with_stats=True)
+    t_exact = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eps, stats = g.epsilon_search(exact=False, with_stats=True)
     t_search = time.perf_counter() - t0
     print("%dx%dx%d after %d iterations: %.4g gaps (an array of %.3g GB), largest %.6g; one pass over them %.3f s "
           "(first, with allocation: %.3f s); search: epsilon = %.17g in %.2f s (%d crossing-outs with %d relaxation "
-          "passes, %d gap passes)" % (W, H, D, iters, count, count * 8 / 1e9, largest, t_pass2, t_pass, eps, t_search,
-                                      stats["crossing_outs"], stats["relaxation_passes"], stats["gap_passes"]), flush=True)
+          "passes, %d gap passes); with the reference's comparisons: epsilon = %.17g in %.2f s (%d crossing-outs, %d relaxation "
+          "passes)" % (W, H, D, iters, count, count * 8 / 1e9, largest, t_pass2, t_pass, eps, t_search,
+                       stats["crossing_outs"], stats["relaxation_passes"], stats["gap_passes"], eps_x, t_exact,
+                       stats_x["crossing_outs"], stats_x["relaxation_passes"]), flush=True)
     g.close()
