@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -79,7 +80,7 @@ struct ds_handle {
         // launched (launch_fused2_rows): the whole interior, or its parts in a deep-halo step
         struct Segments {
             int row_begin = 0, row_end = 0, segs = 0;
-            int seg_begin[17] = {};  // unequal segments when seg_count > 0
+            int seg_begin[65] = {};  // unequal segments when seg_count > 0
             int seg_count = 0;
         } cached[6];
         int cached_n = 0;
@@ -104,6 +105,9 @@ struct ds_handle {
     void *co_gmin = nullptr;                          // [2][Hb][Wh][4] min edge penalty per (pixel, slot)
     uint8_t *co_host_order = nullptr;                 // [Hb][W][D], only when the mask is asked for
     int *co_flags = nullptr;                          // [0] changed, [1] some pixel empty
+    uint8_t *co_dirty = nullptr;                      // [2][Hb][grid_x]: blocks that deleted something, last pass / this pass
+    int co_prev = 0;                                  // which half of co_dirty the next pass reads
+    bool co_dirty_all = true;                         // masks changed outside the whole-band passes: every block is due
     long long *co_state = nullptr;                    // co_fix_kernel's report, [2]
     double co_epsilon = 0.0;
     long long raster_pending = 0;                     // iterations asked for by ds_iterate_raster_async, not yet queued
@@ -292,6 +296,7 @@ void release(ds_handle *h)
     (void)hipFree(h->co_gmin);
     (void)hipFree(h->co_host_order);
     (void)hipFree(h->co_flags);
+    (void)hipFree(h->co_dirty);
     (void)hipFree(h->co_state);
     (void)hipFree(h->eps_buf[0]);
     (void)hipFree(h->eps_buf[1]);
@@ -682,11 +687,14 @@ int launch_fused2_rows(ds_handle *h, int row_begin, int row_end)
     } else if ((long long)p.strips * segs < 4ll * h->cu_count && !std::getenv("DS_FUSED2_ROWS")) {
         long long best = -1;
         std::vector<long long> cu((size_t)h->cu_count);
-        for (int k = 1; k <= 16 && k * 8 <= rows; ++k) {
+        int max_segs = 16;
+        if (const char *m = std::getenv("DS_FUSED2_MAXSEGS"))  // tuning knob: at most this many unequal segments (<= 64)
+            max_segs = std::max(1, std::min(64, std::atoi(m)));
+        for (int k = 1; k <= max_segs && k * 8 <= rows; ++k) {
             for (int f10 = 10; f10 >= 1; --f10) {
                 if (k == 1 && f10 < 10) break;
                 // lengths proportional to 1 - (1 - f) i / (k - 1)
-                int len[16], sum = 0;
+                int len[64], sum = 0;
                 double total = 0.;
                 for (int i = 0; i < k; ++i) total += 1. - (1. - f10 / 10.) * (k > 1 ? (double)i / (k - 1) : 0.);
                 bool usable = true;
@@ -1810,21 +1818,23 @@ int ds_info(const ds_handle *h, int *H, int *W, int *D, int *dtype, int *row_beg
 
 // The crossing-out state of a handle (masks, pair minima, flags), allocated on first use and
 // cleared: all labels dead, the mask's halo rows all alive.
-static int co_state(ds_handle *h, const ds::Geometry &g, double epsilon)
+static int co_prepare(ds_handle *h, const ds::Geometry &g, double epsilon)
 {
     const size_t mask_bytes = (size_t)(2 * ds::mask_colour_stride(g));
     h->co_begun = false;
-    if (!h->co_alive || !h->co_gmin || !h->co_flags) {
-        // all three or none: a failure must not leave a half-allocated state behind that a
+    if (!h->co_alive || !h->co_gmin || !h->co_flags || !h->co_dirty) {
+        // all or none: a failure must not leave a half-allocated state behind that a
         // later call would take for complete
-        void *alive = nullptr, *gmin = nullptr, *flags = nullptr;
+        void *alive = nullptr, *gmin = nullptr, *flags = nullptr, *dirty = nullptr;
         hipError_t e = hipMalloc(&alive, mask_bytes);
         if (e == hipSuccess) e = hipMalloc(&gmin, (size_t)2 * g.Hb * g.Wh * 4 * h->elem);
         if (e == hipSuccess) e = hipMalloc(&flags, 2 * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc(&dirty, (size_t)2 * g.Hb * h->grid_x);
         if (e != hipSuccess) {
             (void)hipFree(alive);
             (void)hipFree(gmin);
             (void)hipFree(flags);
+            (void)hipFree(dirty);
             (void)hipGetLastError();
             return fail(h, e == hipErrorOutOfMemory ? DS_ERR_NOMEM : DS_ERR_HIP,
                         std::string("hipMalloc(crossing-out state): ") + hipGetErrorString(e));
@@ -1832,12 +1842,15 @@ static int co_state(ds_handle *h, const ds::Geometry &g, double epsilon)
         (void)hipFree(h->co_alive);
         (void)hipFree(h->co_gmin);
         (void)hipFree(h->co_flags);
+        (void)hipFree(h->co_dirty);
         h->co_alive = static_cast<uint8_t *>(alive);
         h->co_gmin = gmin;
         h->co_flags = static_cast<int *>(flags);
+        h->co_dirty = static_cast<uint8_t *>(dirty);
     }
     h->co_epsilon = epsilon;
     h->co_fixed = false;
+    h->co_dirty_all = true;  // the first pass looks at every pixel
     HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
     // Halo rows start all-alive: until the neighbouring band's rows arrive they must not
     // take support away (deletions cannot be undone; a late deletion only costs a pass).
@@ -1869,7 +1882,7 @@ int ds_co_begin(ds_handle *h, double epsilon)
     int rc = need_current(h, "ds_co_begin");
     if (rc == DS_OK) rc = use_device(h);
     if (rc != DS_OK) return rc;
-    rc = co_state(h, g, epsilon);
+    rc = co_prepare(h, g, epsilon);
     if (rc != DS_OK) return rc;
     const dim3 grid(h->grid_x, g.Hb), block(ds::kBlock);
     for (int colour = 0; colour < 2; ++colour) {
@@ -1884,6 +1897,28 @@ int ds_co_begin(ds_handle *h, double epsilon)
         HIPCHK(h, hipGetLastError());
     }
     h->co_begun = true;
+    return DS_OK;
+}
+
+// The dirty flags a whole-band relaxation pass reads and writes (co_block_dirty in kernels.hpp), or
+// two null pointers where they do not apply: a band with neighbours gets mask rows from them between
+// passes, which no flag of its own records (DS_CO_DIRTY=off: nowhere, for checking).
+static int co_dirty_flags(ds_handle *h, const uint8_t **prev, uint8_t **cur)
+{
+    *prev = nullptr;
+    *cur = nullptr;
+    const ds::Geometry g = own_view(h);
+    if (g.row0 != 0 || g.Hb != g.H) return DS_OK;
+    if (const char *e = std::getenv("DS_CO_DIRTY"))
+        if (std::strcmp(e, "off") == 0) return DS_OK;
+    const size_t half = (size_t)g.Hb * h->grid_x;
+    uint8_t *p = h->co_dirty + (size_t)h->co_prev * half, *c = h->co_dirty + (size_t)(1 - h->co_prev) * half;
+    if (h->co_dirty_all) HIPCHK(h, hipMemsetAsync(p, 1, half, h->stream));
+    HIPCHK(h, hipMemsetAsync(c, 0, half, h->stream));
+    h->co_dirty_all = false;
+    h->co_prev = 1 - h->co_prev;  // what this pass writes is what the next one reads
+    *prev = p;
+    *cur = c;
     return DS_OK;
 }
 
@@ -1908,13 +1943,17 @@ static int co_launch_pass(ds_handle *h, int radius = -1, int wi = 0, int wj = 0)
     }
     const dim3 grid(segs, rows), block(ds::kBlock);
     HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
+    const uint8_t *dirty_prev = nullptr;
+    uint8_t *dirty_cur = nullptr;
+    if (radius >= 0) h->co_dirty_all = true;  // a windowed pass keeps no flags: the next whole pass looks everywhere
+    else if (co_dirty_flags(h, &dirty_prev, &dirty_cur) != DS_OK) return DS_ERR_HIP;
     for (int colour = 0; colour < 2; ++colour) {
         int rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
             hipLaunchKernelGGL((ds::co_relax_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
                                static_cast<const T *>(h->phi), (T)h->lambda, (T)h->co_epsilon, colour,
                                h->seg_pixels, h->co_alive, static_cast<const T *>(h->co_gmin), h->co_flags, row_first,
-                               seg_first, col_lo, col_hi);
+                               seg_first, col_lo, col_hi, dirty_prev, dirty_cur, h->grid_x);
             return DS_OK;
         });
         if (rc != DS_OK) return rc;
@@ -2088,6 +2127,7 @@ int ds_find_best_labeling(ds_handle *h, int max_passes, uint32_t *labels, int *n
         }
         if (st[0] == 1) {  // labels were crossed out: back to the fixed point (crossing_out, :135-183)
             ++chosen;
+            h->co_dirty_all = true;  // a mask changed outside the relaxation passes
             // Only the chosen pixel's mask changed, and a deletion can only follow a deletion at a
             // neighbour: pass k need not look further than k pixels from the chosen one (and changes
             // nothing outside that window), and a pass that deletes nothing has reached the fixed
@@ -2225,7 +2265,7 @@ int ds_epsilon_gaps_fetch(ds_handle *h, double *out)
 static int eps_query(ds_handle *h, double lo, double *mins, int have_mins, unsigned long long *result, double out[3])
 {
     const ds::Geometry &g = h->g;
-    const unsigned long long init[3] = {0x7ff0000000000000ull, 0ull, 0ull};  // +inf, +0, 0
+    static const unsigned long long init[3] = {0x7ff0000000000000ull, 0ull, 0ull};  // +inf, +0, 0
     HIPCHK(h, hipMemcpyAsync(result, init, sizeof init, hipMemcpyHostToDevice, h->stream));
     int shift = 0;
     while ((1 << shift) < g.D) ++shift;
@@ -2269,7 +2309,7 @@ static int crossing_out_exact(ds_handle *h, double epsilon, const double *mins, 
                               uint8_t *alive_out, int *not_empty, int *passes)
 {
     const ds::Geometry &g = h->g;
-    int rc = co_state(h, g, epsilon);
+    int rc = co_prepare(h, g, epsilon);
     if (rc != DS_OK) return rc;
     // the O(D) kernels' pair minima as well, so that every entry point that continues on these
     // masks (ds_find_best_labeling, ds_co_pass) finds the state it expects
@@ -2290,12 +2330,17 @@ static int crossing_out_exact(ds_handle *h, double epsilon, const double *mins, 
     const size_t lds = (size_t)g.D * (8 * sizeof(double) + sizeof(int) + 5) + 8;
     const dim3 grid((unsigned)((size_t)g.H * g.W));
     auto launch = [&](int phase) -> int {
+        const uint8_t *dirty_prev = nullptr;
+        uint8_t *dirty_cur = nullptr;
+        if (phase == 1 && co_dirty_flags(h, &dirty_prev, &dirty_cur) != DS_OK) return DS_ERR_HIP;
         if (h->dtype == DS_F64)
             hipLaunchKernelGGL(ds::co_exact_kernel<double>, grid, block, lds, h->stream, g, static_cast<const double *>(h->phi),
-                               h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase);
+                               h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase, dirty_prev,
+                               dirty_cur, h->seg_pixels, h->grid_x);
         else
             hipLaunchKernelGGL(ds::co_exact_kernel<float>, grid, block, lds, h->stream, g, static_cast<const float *>(h->phi),
-                               h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase);
+                               h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase, dirty_prev,
+                               dirty_cur, h->seg_pixels, h->grid_x);
         HIPCHK(h, hipGetLastError());
         return DS_OK;
     };
@@ -2396,13 +2441,19 @@ int ds_epsilon_search(ds_handle *h, int exact, int max_passes, double *epsilon, 
         return code;
     };
     // the predicate of epsilon_search.rs:100-102: initialize_with_epsilon, crossing_out, is_not_empty
+    const bool verbose = std::getenv("DS_EPSILON_SEARCH_LOG") != nullptr;  // one line per question, on stderr
     auto ask = [&](bool by_reference, double eps, bool &yes) {
         int not_empty = 0, passes = 0;
+        const auto t0 = std::chrono::steady_clock::now();
         const int r = by_reference ? crossing_out_exact(h, eps, mins, max_passes, nullptr, nullptr, &not_empty, &passes)
                                    : ds_crossing_out(h, eps, max_passes, nullptr, nullptr, &not_empty, &passes);
         ++predicates;
         passes_total += passes;
         yes = not_empty != 0;
+        if (verbose)
+            std::fprintf(stderr, "ds_epsilon_search: epsilon %.17g (%s comparisons): %s after %d passes, %.3f s\n", eps,
+                         by_reference ? "the reference's" : "O(D)", yes ? "not empty" : "empty", passes,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         return r;
     };
     auto consistent = [&](double eps, bool &yes) { return ask(exact != 0, eps, yes); };

@@ -139,7 +139,7 @@ template <typename T, int NP, int DL> struct Fused2Lds {
 // few rounds of blocks: n = 0 means equal segments of rows_per_seg rows.
 struct RowSegments {
     int n;
-    int begin[17];
+    int begin[65];
 };
 
 // PARTIAL: D < 4 LPP, D a multiple of 4.  The lanes of a slot beyond its D / 4 label

@@ -1003,6 +1003,20 @@ __device__ __forceinline__ long long mask_off(const Geometry &g, const Pixel &p,
     }
 }
 
+// dirty flags of the relaxation passes: one byte per (band row, row segment); `prev` holds the
+// blocks that deleted something in the previous pass, `cur` those that have in this one.
+__device__ __forceinline__ bool co_block_dirty(const uint8_t *prev, const uint8_t *cur, long long at, int r, int seg,
+                                               int rows, int nseg)
+{
+    const volatile uint8_t *now = cur;
+    int run = prev[at] | now[at];
+    if (seg > 0) run |= prev[at - 1] | now[at - 1];
+    if (seg + 1 < nseg) run |= prev[at + 1] | now[at + 1];
+    if (r > 0) run |= prev[at - nseg] | now[at - nseg];
+    if (r + 1 < rows) run |= prev[at + nseg] | now[at + nseg];
+    return run != 0;
+}
+
 // First pass: vertex mask and gmin[t][n]; mode bit: see co_relax_kernel.
 template <typename T, int LPP>
 __global__ __launch_bounds__(kBlock) void co_init_kernel(Geometry g, const T *__restrict__ phi,
@@ -1075,7 +1089,8 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
                                                           T eps, int colour, int seg_pixels,
                                                           uint8_t *alive, const T *__restrict__ gmin,
                                                           int *__restrict__ changed, int row_first, int seg_first,
-                                                          int col_lo, int col_hi)
+                                                          int col_lo, int col_hi, const uint8_t *dirty_prev,
+                                                          uint8_t *dirty_cur, int nseg)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP;
@@ -1084,6 +1099,12 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
     const int q = lane / LPP, lseg = lane % LPP, d0 = 4 * lseg;
     const int i = row_first + blockIdx.y;  // the grid may cover a window of the band only
     const int s = (i + colour) & 1;
+    // A pixel's answer can only change after a neighbour's mask has: a block whose own pixels and
+    // whose four neighbouring blocks (same rows of the segments beside it, same segment of the rows
+    // above and below) changed nothing in the previous pass, nor yet in this one, has nothing to do.
+    // Deletions travel one or two pixels per pass, so late passes are thin fronts.
+    const long long flag_at = (long long)(i - g.row0) * nseg + seg_first + (int)blockIdx.x;
+    if (dirty_prev && !co_block_dirty(dirty_prev, dirty_cur, flag_at, i - g.row0, seg_first + (int)blockIdx.x, g.Hb, nseg)) return;
     T lam[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
@@ -1139,7 +1160,10 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
         for (int m = LPP / 2; m >= 1; m >>= 1) left_alive |= __shfl_xor(left_alive, m);
         if (p.j < g.W && inside && lseg == 0 && left_alive == 0u) lost = true;
     }
-    if (__any(any) && lane == 0) atomicOr(changed, 1);
+    if (__any(any) && lane == 0) {
+        atomicOr(changed, 1);
+        if (dirty_cur) dirty_cur[flag_at] = 1;
+    }
     if (__any(lost) && lane == 0) atomicOr(changed + 1, 1);
 }
 
@@ -1543,7 +1567,9 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *__restrict__ phi,
                                                           const uint8_t *__restrict__ cost, double lambda, double eps,
                                                           int shift, const double *__restrict__ mins, uint8_t *alive,
-                                                          int *__restrict__ changed, int phase)
+                                                          int *__restrict__ changed, int phase,
+                                                          const uint8_t *dirty_prev, uint8_t *dirty_cur, int seg_pixels,
+                                                          int nseg)
 {
     extern __shared__ double eps_lds[];
     const int D = g.D;
@@ -1560,6 +1586,11 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
     const int ni[4] = {i, i - 1, i, i + 1}, nj[4] = {j - 1, j, j + 1, j};
     const long long own_off = (long long)il * g.row_stride + (long long)jc * g.Dpad;
     uint8_t *alive_t = mask_base(g, alive, colour) + ((long long)(i - g.row0) * g.Wh + jc) * g.Dpad;
+    // the O(D) passes' dirty flags (co_block_dirty), at their granularity
+    const long long flag_at = (long long)(i - g.row0) * nseg + jc / seg_pixels;
+    if (phase == 1 && dirty_prev &&
+        !co_block_dirty(dirty_prev, dirty_cur, flag_at, i - g.row0, jc / seg_pixels, g.Hb, nseg))
+        return;
 
     for (int e = tid; e < 4 * D; e += kBlock) {
         const int n = e / D, d = e % D;
@@ -1643,7 +1674,10 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
     }
     died = __any(died);
     left = __any(left);
-    if (lane == 0 && died) atomicOr(changed, 1);
+    if (lane == 0 && died) {
+        atomicOr(changed, 1);
+        if (dirty_cur) dirty_cur[flag_at] = 1;
+    }
     // "the pixel has no vertex left" needs all wavefronts: count those that still hold one
     __shared__ int holders;
     if (tid == 0) holders = 0;

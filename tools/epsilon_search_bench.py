@@ -2,6 +2,7 @@
 images whose array cannot exist.  env SIZES = "H,W,D;...", ITERS = diffusion iterations before."""
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +12,16 @@ from __graft_entry__ import load_package  # noqa: E402
 load_package()
 from stereo_vision_amd import diffstereo, synth  # noqa: E402
 
+
+
+def heartbeat():
+    t0 = time.perf_counter()
+    while True:
+        time.sleep(30)
+        print("... %.0f s" % (time.perf_counter() - t0), flush=True)
+
+
+threading.Thread(target=heartbeat, daemon=True).start()
 sizes = os.environ.get("SIZES", "400,400,40;1080,1920,128")
 iters = int(os.environ.get("ITERS", "200"))
 for spec in sizes.split(";"):
@@ -25,9 +36,11 @@ for spec in sizes.split(";"):
     t0 = time.perf_counter()
     nxt, largest, count = g.epsilon_next(largest)
     t_pass2 = time.perf_counter() - t0
+    print("%dx%dx%d: one pass over the gaps %.3f s" % (W, H, D, t_pass2), flush=True)
     t0 = time.perf_counter()
     eps_x, stats_x = g.epsilon_search(exact=True, with_stats=True)
     t_exact = time.perf_counter() - t0
+    print("%dx%dx%d: search with the reference's comparisons %.2f s" % (W, H, D, t_exact), flush=True)
     t0 = time.perf_counter()
     eps, stats = g.epsilon_search(exact=False, with_stats=True)
     t_search = time.perf_counter() - t0
