@@ -218,8 +218,8 @@ def kernel_account(graph, steps, dtype, D, H, W, workload, world):
         # launch, 4 rows of the second colour read + 4 written (4*sizeof(T), half the pixels are
         # of that colour) + the cost byte of both iterations.
         bytes_per_pl = 4 * elem + 2
-        kernel = "ds::fused2_iteration_kernel<%s, %d, %d, %s>" % (tname, lpp, 12 if dtype == "f32" else 8,
-                                                                  "false" if D == 4 * lpp else "true")
+        kernel = "ds::fused2_iteration_kernel<%s, %d, %d, %d>" % (tname, lpp, 12 if dtype == "f32" else 8,
+                                                                  0 if D == 4 * lpp else 1 if D % 4 == 0 else 2)
         kernel_s, launches, per_launch = ms2 / 1e3, n2, 2
         # valid (pixel, label) pairs of the interior region: column j has min(j, D - 1) + 1 labels.
         # A step covers the region once: in one launch, or (deep-halo bands) in up to three

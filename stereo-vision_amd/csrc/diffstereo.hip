@@ -80,7 +80,7 @@ struct ds_handle {
         // launched (launch_fused2_rows): the whole interior, or its parts in a deep-halo step
         struct Segments {
             int row_begin = 0, row_end = 0, segs = 0;
-            int seg_begin[65] = {};  // unequal segments when seg_count > 0
+            int seg_begin[17] = {};  // unequal segments when seg_count > 0
             int seg_count = 0;
         } cached[6];
         int cached_n = 0;
@@ -573,14 +573,14 @@ void plan_fused2(ds_handle *h)
     const ds::Geometry &g = h->g;
     const char *e = std::getenv("DS_FUSED2");
     if (e && std::strcmp(e, "off") == 0) return;
-    // D fills the lanes of a pixel slot (64 / 128 / 256), or fills the lower ones in whole lanes (a
-    // multiple of 4: the kernel's PARTIAL instantiation); other D keep one iteration per launch
+    // D fills the lanes of a pixel slot (64 / 128 / 256), or only the lower ones (any other D: the
+    // kernel's PARTIAL instantiation)
     // f64: 8-wavefront blocks (the registers of a 12-wavefront block do not hold f64 rows); 4K x 256:
     // 10.4 ms per iteration against 13.7 for one iteration per launch on the same device.
     // DS_FUSED2_F64=off keeps f64 to one iteration per launch.
     const char *f64 = std::getenv("DS_FUSED2_F64");
-    const bool f64_probe = h->dtype == DS_F64 && !(f64 && std::strcmp(f64, "off") == 0) && h->fused_waves == 8 && g.D % 4 == 0;
-    if (!f64_probe && (h->dtype != DS_F32 || h->fused_waves != 16 || g.D % 4 != 0)) return;
+    const bool f64_probe = h->dtype == DS_F64 && !(f64 && std::strcmp(f64, "off") == 0) && h->fused_waves == 8;
+    if (!f64_probe && (h->dtype != DS_F32 || h->fused_waves != 16)) return;
     if (const char *pd = std::getenv("DS_FUSED2_PARTIAL"))  // checking knob: off = only D = 4 LPP
         if (std::strcmp(pd, "off") == 0 && g.D != 4 * h->lpp) return;
     p.waves = f64_probe ? 8 : 12;
@@ -687,14 +687,11 @@ int launch_fused2_rows(ds_handle *h, int row_begin, int row_end)
     } else if ((long long)p.strips * segs < 4ll * h->cu_count && !std::getenv("DS_FUSED2_ROWS")) {
         long long best = -1;
         std::vector<long long> cu((size_t)h->cu_count);
-        int max_segs = 16;
-        if (const char *m = std::getenv("DS_FUSED2_MAXSEGS"))  // tuning knob: at most this many unequal segments (<= 64)
-            max_segs = std::max(1, std::min(64, std::atoi(m)));
-        for (int k = 1; k <= max_segs && k * 8 <= rows; ++k) {
+        for (int k = 1; k <= 16 && k * 8 <= rows; ++k) {
             for (int f10 = 10; f10 >= 1; --f10) {
                 if (k == 1 && f10 < 10) break;
                 // lengths proportional to 1 - (1 - f) i / (k - 1)
-                int len[64], sum = 0;
+                int len[16], sum = 0;
                 double total = 0.;
                 for (int i = 0; i < k; ++i) total += 1. - (1. - f10 / 10.) * (k > 1 ? (double)i / (k - 1) : 0.);
                 bool usable = true;
@@ -748,15 +745,18 @@ int launch_fused2_rows(ds_handle *h, int row_begin, int row_end)
     const dim3 grid(p.strips, segs), block(64 * p.waves);
     float *base = static_cast<float *>(h->phi);
     const float lambda = (float)h->lambda;
-    const bool partial = g.D != 4 * h->lpp;
+    // 0: D fills the slot's lanes; 1: the lower lanes, whole ones; 2: the last of them partly
+    const int partial = g.D == 4 * h->lpp ? 0 : g.D % 4 == 0 ? 1 : 2;
     auto go = [&](auto lppc, auto wavesc) {
         constexpr int L = decltype(lppc)::value, FW = decltype(wavesc)::value;
-        if (partial)
-            hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, L, FW, true>), grid, block, 0, h->stream, in, base, base,
-                               np, h->cost_px, lambda, p.cL, row_begin, row_end, rows_per_seg, table, h->store_first ? 1 : 0);
-        else
-            hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, L, FW, false>), grid, block, 0, h->stream, in, base, base,
-                               np, h->cost_px, lambda, p.cL, row_begin, row_end, rows_per_seg, table, h->store_first ? 1 : 0);
+        auto launch = [&](auto mode) {
+            hipLaunchKernelGGL((ds::fused2_iteration_kernel<float, L, FW, decltype(mode)::value>), grid, block, 0, h->stream,
+                               in, base, base, np, h->cost_px, lambda, p.cL, row_begin, row_end, rows_per_seg, table,
+                               h->store_first ? 1 : 0);
+        };
+        if (partial == 0) launch(std::integral_constant<int, 0>{});
+        else if (partial == 1) launch(std::integral_constant<int, 1>{});
+        else launch(std::integral_constant<int, 2>{});
     };
     auto with_waves = [&](auto lppc) {
         if (p.waves == 12) go(lppc, std::integral_constant<int, 12>{});
@@ -765,14 +765,14 @@ int launch_fused2_rows(ds_handle *h, int row_begin, int row_end)
     if (h->dtype == DS_F64) {  // the probe: 8 wavefronts
         double *b64 = static_cast<double *>(h->phi);
         auto go64 = [&](auto lppc) {
-            if (partial)
-                hipLaunchKernelGGL((ds::fused2_iteration_kernel<double, decltype(lppc)::value, 8, true>), grid, block, 0, h->stream,
-                                   in, b64, b64, np, h->cost_px, h->lambda, p.cL, row_begin, row_end, rows_per_seg, table,
-                                   h->store_first ? 1 : 0);
-            else
-                hipLaunchKernelGGL((ds::fused2_iteration_kernel<double, decltype(lppc)::value, 8, false>), grid, block, 0, h->stream,
-                                   in, b64, b64, np, h->cost_px, h->lambda, p.cL, row_begin, row_end, rows_per_seg, table,
-                                   h->store_first ? 1 : 0);
+            auto launch = [&](auto mode) {
+                hipLaunchKernelGGL((ds::fused2_iteration_kernel<double, decltype(lppc)::value, 8, decltype(mode)::value>), grid,
+                                   block, 0, h->stream, in, b64, b64, np, h->cost_px, h->lambda, p.cL, row_begin, row_end,
+                                   rows_per_seg, table, h->store_first ? 1 : 0);
+            };
+            if (partial == 0) launch(std::integral_constant<int, 0>{});
+            else if (partial == 1) launch(std::integral_constant<int, 1>{});
+            else launch(std::integral_constant<int, 2>{});
         };
         switch (h->lpp) {
         case 16: go64(std::integral_constant<int, 16>{}); break;

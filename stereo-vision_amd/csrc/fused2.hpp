@@ -139,14 +139,16 @@ template <typename T, int NP, int DL> struct Fused2Lds {
 // few rounds of blocks: n = 0 means equal segments of rows_per_seg rows.
 struct RowSegments {
     int n;
-    int begin[65];
+    int begin[17];
 };
 
-// PARTIAL: D < 4 LPP, D a multiple of 4.  The lanes of a slot beyond its D / 4 label
-// lanes load from clamped addresses, store nothing and keep out of the other lanes' minima
-// (messages_lean); everything else is the D = 4 LPP kernel.  A separate instantiation, so that
-// kernel's code does not change.
-template <typename T, int LPP, int FW, bool PARTIAL = false>
+// PARTIAL != 0: D < 4 LPP.  The lanes of a slot beyond its label lanes (Dpad / 4 of them, Dpad = D
+// rounded up to 4) load from clamped addresses, store nothing and keep out of the other lanes'
+// minima (messages_lean); PARTIAL == 2: D is not a multiple of 4 either, and the padding labels
+// (D <= d < Dpad) are put back to +inf after every update; everything else is the D = 4 LPP
+// kernel.  Separate instantiations, so that kernel's code does not change (a condition more in
+// the source moves its register allocation, even one that folds away).
+template <typename T, int LPP, int FW, int PARTIAL = 0>
 __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, const T *__restrict__ phi,
                                                                    T *__restrict__ phi_out, FusedPlanes np,
                                                                    const uint8_t *__restrict__ cost, T lambda,
@@ -162,8 +164,8 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     const int q = lane / LPP, lseg = lane % LPP;
     // d0: the lane's first label as an address (PARTIAL: clamped into the slot's row); lane_on: the
     // lane holds labels
-    const bool lane_on = !PARTIAL || 4 * lseg < g.Dpad;
-    const int d0 = PARTIAL ? (4 * lseg < g.Dpad ? 4 * lseg : g.Dpad - 4) : 4 * lseg;
+    const bool lane_on = PARTIAL == 0 || 4 * lseg < g.Dpad;
+    const int d0 = PARTIAL != 0 ? (4 * lseg < g.Dpad ? 4 * lseg : g.Dpad - 4) : 4 * lseg;
     const int dl = 4 * lseg;  // the lane's place in an LDS row
     const int kp = wave * PPW + q;
     // the slots of this wavefront, as scalars: a stage skips a wavefront none of whose slots it
@@ -189,12 +191,17 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
     // is the same (the labels that do not exist hold +inf in memory and drop out of every
     // minimum); only the results for such labels are put back to +inf (the sums above them may be
     // inf - inf).  One scalar branch per update for the other strips.
-    const bool few_labels = c0 - 1 < g.D;
+    // PARTIAL == 2: the last label lane also holds padding labels, which take the same way (they
+    // hold +inf in memory and must hold it again after every update).
+    const bool few_labels = [&]() {
+        if constexpr (PARTIAL == 2) return true;
+        else return c0 - 1 < g.D;
+    }();
     auto update = [&](const V psi[4], uint32_t cost_word, int j, V out[4]) {
         V M[4];
         const V qc = unpack_cost<T>(cost_word);
-        if constexpr (sizeof(T) == 4) messages_lean<LPP, PARTIAL>(psi, lam, lambda, lseg, rev4, M, lane_on);
-        else messages<T, LPP, PARTIAL>(psi, lam, lambda, lseg, lane, M, lane_on);
+        if constexpr (sizeof(T) == 4) messages_lean<LPP, PARTIAL != 0>(psi, lam, lambda, lseg, rev4, M, lane_on);
+        else messages<T, LPP, PARTIAL != 0>(psi, lam, lambda, lseg, lane, M, lane_on);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const T avg = (qc.v[c] + (((M[0].v[c] + M[1].v[c]) + M[2].v[c]) + M[3].v[c])) * T(0.25);
@@ -202,9 +209,11 @@ __global__ __launch_bounds__(64 * FW) void fused2_iteration_kernel(Geometry g, c
             for (int n = 0; n < 4; ++n) out[n].v[c] = avg - M[n].v[c];
         }
         if (few_labels) {
+            int last = j;  // the pixel's last label
+            if constexpr (PARTIAL == 2) last = j > g.D - 1 ? g.D - 1 : j;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const bool valid = dl + c <= j;
+                const bool valid = dl + c <= last;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) out[n].v[c] = valid ? out[n].v[c] : inf;
             }

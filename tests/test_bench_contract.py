@@ -20,7 +20,7 @@ def test_valid_pairs_counts_labels_up_to_the_column_index():
 
 
 def test_committed_traffic_record_matches_the_dominant_kernels():
-    t = bench.pmc_traffic("4k_256", "ds::fused2_iteration_kernel<float, 64, 12, false>")
+    t = bench.pmc_traffic("4k_256", "ds::fused2_iteration_kernel<float, 64, 12, 0>")
     assert t is not None and t > 3.0e10
     assert bench.pmc_traffic("4k_256", "ds::no_such_kernel") is None
     for name, w in bench.WORKLOADS.items():

@@ -200,7 +200,9 @@ def _rccl_worker(rank, dtype, D, rows, W, out):
     # bands of 14 rows or more with an interior for the two-iteration kernel (f32, D a multiple of 4,
     # wide enough for a strip) step by two
     by_two = a.fused2_info()["available"] and re - rb >= 14
-    assert by_two == ((W >= 330 or D == 200) and dtype == "f32" and re - rb >= 14), (by_two, dtype, D, rows, W)
+    # the two-iteration kernel needs room for a strip of its slots: 64-label slots (D = 64) do not fit
+    # 96 columns, the single-pixel slots of D = 130 / 200 do; bands under 14 rows step by one
+    assert by_two == ((W >= 330 or D in (130, 200)) and re - rb >= 14), (by_two, dtype, D, rows, W)
     stepped = a.fused2_info()["steps"] == (iters // 2 if by_two else 0)
     out[0] = (bool(same), bool(moved), a.checksum() == b.checksum(), e_a == b.energy() and stepped)
     a.close()

@@ -1,7 +1,7 @@
-"""Two iterations per launch (ds_iterate on handles whose D is a multiple of 4: D = 64 / 128 /
-256 fill the lanes of a pixel slot, other multiples of 4 take the kernel's instantiation for partly
-filled slots; f32 in 12-wavefront blocks, f64 in 8-wavefront blocks) against one iteration per
-launch (DS_FUSED2=off) and the O(D) oracle.  Needs a GPU.
+"""Two iterations per launch (ds_iterate: D = 64 / 128 / 256 fill the lanes of a pixel slot, every
+other D takes the kernel's instantiation for partly filled slots; f32 in 12-wavefront blocks, f64
+in 8-wavefront blocks) against one iteration per launch (DS_FUSED2=off) and the O(D) oracle.
+Needs a GPU.
 
 Bar: bit-identical phi (integer-exact comparison of the float bit patterns via array_equal),
 identical labels, equal energy."""
@@ -21,7 +21,9 @@ from stereo_vision_amd import diffstereo, synth  # noqa: E402
 SHAPES = [(20, 400, 256), (21, 333, 256), (30, 700, 128), (17, 421, 128), (24, 600, 64), (17, 390, 64),
           (45, 330, 256),
           # D below the lanes' capacity: the reference's own 40, and 100 / 200 / 8 / 132 / 60
-          (24, 600, 40), (19, 333, 100), (22, 500, 200), (17, 400, 8), (20, 421, 132), (31, 390, 60)]
+          (24, 600, 40), (19, 333, 100), (22, 500, 200), (17, 400, 8), (20, 421, 132), (31, 390, 60),
+          # D that is not a multiple of 4: the last label lane also holds padding labels
+          (20, 400, 41), (22, 500, 202), (19, 333, 99), (17, 300, 3), (18, 280, 1), (21, 345, 130), (16, 410, 255)]
 
 
 @pytest.mark.parametrize("H,W,D", SHAPES)
@@ -57,8 +59,7 @@ def test_pairs_of_iterations_equal_single_iterations(monkeypatch, H, W, D):
 
 
 def test_handles_without_an_interior_fall_back():
-    for H, W, D, dtype in ((20, 52, 40, "f32"), (11, 400, 256, "f32"), (20, 400, 202, "f32"), (20, 400, 41, "f32"),
-                           (20, 400, 102, "f64"), (20, 400, 41, "f64")):
+    for H, W, D, dtype in ((20, 52, 40, "f32"), (11, 400, 256, "f32"), (20, 60, 41, "f64"), (9, 300, 100, "f64")):
         left, right = random_pair(H, W, seed=3)
         g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
         assert not g.fused2_info()["available"], (H, W, D, dtype)
@@ -185,7 +186,9 @@ def test_partly_filled_slots_can_be_switched_off(monkeypatch):
 @pytest.mark.parametrize("H,W,D", [(20, 200, 256), (26, 300, 128), (21, 333, 64), (33, 521, 256), (40, 197, 64),
                                    # partly filled slots: the reference's own D = 40 in its own precision, and others
                                    (24, 400, 40), (19, 233, 100), (22, 300, 200), (17, 200, 8), (20, 321, 132),
-                                   (31, 290, 60), (18, 150, 40)])
+                                   (31, 290, 60), (18, 150, 40),
+                                   # D that is not a multiple of 4
+                                   (20, 400, 41), (20, 400, 102), (18, 300, 130), (17, 200, 5), (19, 333, 255)])
 def test_f64_pairs_give_the_same_bits(monkeypatch, H, W, D):
     """The two-iteration kernel in f64 (8-wavefront blocks) against one iteration per launch
     (DS_FUSED2_F64=off) and the oracle."""
