@@ -1941,19 +1941,22 @@ static int co_launch_pass(ds_handle *h, int radius = -1, int wi = 0, int wj = 0)
         seg_first = (c0 >> 1) / h->seg_pixels;
         segs = (c1 >> 1) / h->seg_pixels - seg_first + 1;
     }
-    const dim3 grid(segs, rows), block(ds::kBlock);
     HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
     const uint8_t *dirty_prev = nullptr;
     uint8_t *dirty_cur = nullptr;
     if (radius >= 0) h->co_dirty_all = true;  // a windowed pass keeps no flags: the next whole pass looks everywhere
     else if (co_dirty_flags(h, &dirty_prev, &dirty_cur) != DS_OK) return DS_ERR_HIP;
+    // with dirty flags most blocks of a late pass return at once: fewer, longer blocks then (eight
+    // segments each, as long as that leaves thousands of blocks)
+    const int per_block = dirty_prev && (long long)segs * rows >= 65536 ? 8 : 1;
+    const dim3 grid((segs + per_block - 1) / per_block, rows), block(ds::kBlock);
     for (int colour = 0; colour < 2; ++colour) {
         int rc = dispatch(h, [&](auto t, auto lpp) -> int {
             using T = decltype(t);
             hipLaunchKernelGGL((ds::co_relax_kernel<T, decltype(lpp)::value>), grid, block, 0, h->stream, g,
                                static_cast<const T *>(h->phi), (T)h->lambda, (T)h->co_epsilon, colour,
                                h->seg_pixels, h->co_alive, static_cast<const T *>(h->co_gmin), h->co_flags, row_first,
-                               seg_first, col_lo, col_hi, dirty_prev, dirty_cur, h->grid_x);
+                               seg_first, col_lo, col_hi, dirty_prev, dirty_cur, h->grid_x, per_block, seg_first + segs);
             return DS_OK;
         });
         if (rc != DS_OK) return rc;
@@ -2328,7 +2331,7 @@ static int crossing_out_exact(ds_handle *h, double epsilon, const double *mins, 
     int shift = 0;
     while ((1 << shift) < g.D) ++shift;
     const size_t lds = (size_t)g.D * (8 * sizeof(double) + sizeof(int) + 5) + 8;
-    const dim3 grid((unsigned)((size_t)g.H * g.W));
+    const dim3 grid(h->grid_x, g.Hb);
     auto launch = [&](int phase) -> int {
         const uint8_t *dirty_prev = nullptr;
         uint8_t *dirty_cur = nullptr;
@@ -2492,26 +2495,47 @@ int ds_epsilon_search(ds_handle *h, int exact, int max_passes, double *epsilon, 
         return DS_OK;
     };
     // With the reference's comparisons a crossing-out costs O(D^2) per pixel and pass.  The O(D) one
-    // answers the same except within rounding of a gap, so on f64 handles it does the halving and the
-    // reference's comparisons confirm the interval's two ends (and redo the halving on the side that
-    // does not hold: rare, and then only inside an interval that is already small).
+    // answers the same unless a penalty lies within rounding of its threshold, so on f64 handles it
+    // does the halving first.  Where it changes its answer is a gap of the graph moved by that
+    // rounding, so the interval it ends with is widened by a bound on the rounding (a few units in
+    // the last place of the largest penalty: r), the reference's comparisons confirm the wider
+    // interval's two ends (r grows until they do) and finish the halving inside it: about a dozen
+    // crossing-outs of the expensive kind instead of fifty.
     const bool fast_first = exact && h->dtype == DS_F64;
     rc = halve(exact && !fast_first);
     if (rc != DS_OK) return done(rc);
     if (fast_first) {
-        bool lo_passes = false, hi_passes = true;
-        if (lo > smallest) rc = ask(true, lo, lo_passes);
-        if (rc == DS_OK && hi < largest) rc = ask(true, hi, hi_passes);
-        if (rc != DS_OK) return done(rc);
-        if (lo_passes) {
-            hi = lo;
-            lo = smallest;
-            rc = halve(true);
-        } else if (!hi_passes) {
-            lo = hi;
-            hi = largest;
-            rc = halve(true);
+        double r = 1e-12 * (255.0 + std::fabs(h->lambda) * (g.D - 1));
+        double lo_known = smallest, hi_known = largest;  // the reference's comparisons: fails at lo_known, passes at hi_known (or it is `largest`)
+        const double lo_fast = lo, hi_fast = hi;
+        bool lo_set = false, hi_set = false;
+        for (int grow = 0; grow < 40 && !(lo_set && hi_set); ++grow, r *= 16.0) {
+            if (!lo_set) {
+                const double x = lo_fast - r;
+                if (!(x > lo_known)) lo_set = true;  // back at a point that is known to fail
+                else {
+                    rc = ask(true, x, yes);
+                    if (rc != DS_OK) return done(rc);
+                    if (yes) hi_known = std::min(hi_known, x), hi_set = true;  // the answer lies below
+                    else lo_known = x, lo_set = true;
+                }
+            }
+            if (!hi_set) {
+                const double x = hi_fast + r;
+                if (!(x < hi_known)) hi_set = true;
+                else {
+                    rc = ask(true, x, yes);
+                    if (rc != DS_OK) return done(rc);
+                    if (yes) hi_known = x, hi_set = true;
+                    else lo_known = std::max(lo_known, x), lo_set = true;  // the answer lies above
+                }
+            }
+            // an end that turned out to lie on the wrong side moved the other end's known point: look again
+            if (lo_set && hi_set && !(lo_known < hi_known)) return done(fail(h, DS_ERR_STATE, "ds_epsilon_search: the predicate is not monotone"));
         }
+        lo = lo_known;
+        hi = hi_known;
+        rc = halve(true);
         if (rc != DS_OK) return done(rc);
     }
     for (int it = 0; it < 64; ++it) {

@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
                                                           uint8_t *alive, const T *__restrict__ gmin,
                                                           int *__restrict__ changed, int row_first, int seg_first,
                                                           int col_lo, int col_hi, const uint8_t *dirty_prev,
-                                                          uint8_t *dirty_cur, int nseg)
+                                                          uint8_t *dirty_cur, int nseg, int segs_per_block, int seg_end)
 {
     using R = Real<T>;
     constexpr int PPW = 64 / LPP;
@@ -1103,8 +1103,12 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
     // whose four neighbouring blocks (same rows of the segments beside it, same segment of the rows
     // above and below) changed nothing in the previous pass, nor yet in this one, has nothing to do.
     // Deletions travel one or two pixels per pass, so late passes are thin fronts.
-    const long long flag_at = (long long)(i - g.row0) * nseg + seg_first + (int)blockIdx.x;
-    if (dirty_prev && !co_block_dirty(dirty_prev, dirty_cur, flag_at, i - g.row0, seg_first + (int)blockIdx.x, g.Hb, nseg)) return;
+    // A block takes segs_per_block consecutive segments of its row, one after the other: late passes
+    // are launches of blocks that return, and cost what launching them costs.
+    for (int seg = seg_first + (int)blockIdx.x * segs_per_block;
+         seg < seg_first + ((int)blockIdx.x + 1) * segs_per_block && seg < seg_end; ++seg) {
+    const long long flag_at = (long long)(i - g.row0) * nseg + seg;
+    if (dirty_prev && !co_block_dirty(dirty_prev, dirty_cur, flag_at, i - g.row0, seg, g.Hb, nseg)) continue;
     T lam[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
@@ -1112,7 +1116,7 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
     const uint8_t *alive_o = mask_base(g, alive, 1 - colour);
     const T *gmin_c = gmin + (long long)colour * g.Hb * g.Wh * 4;
 
-    const int seg0 = (seg_first + blockIdx.x) * seg_pixels;
+    const int seg0 = seg * seg_pixels;
     const int groups = seg_pixels / PPW;
     bool any = false, lost = false;
     for (int grp = wave; grp < groups; grp += kBlock / 64) {
@@ -1165,6 +1169,7 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
         if (dirty_cur) dirty_cur[flag_at] = 1;
     }
     if (__any(lost) && lane == 0) atomicOr(changed + 1, 1);
+    }
 }
 
 // Smallest alive label per pixel (crossing_out_graph.rs:307-327); 0xffffffff and
@@ -1560,8 +1565,9 @@ __global__ __launch_bounds__(kBlock) void eps_query_kernel(Geometry g, const T *
 //   edge_exists and A_t and (vertex (t', d') alive or not A_t').
 // That condition is monotone in the vertex masks, so in-place passes in any order reach the
 // reference's fixed point.  mins[pixel][5]: vertex minimum and pair minima (eps_query_kernel).
-// phase 0 writes the vertex masks, phase 1 is one relaxation pass.  One block per pixel; a thread
-// keeps one d' (the low `shift` bits of its index) and walks d in steps of kBlock >> shift.
+// phase 0 writes the vertex masks, phase 1 is one relaxation pass.  A block takes a row segment (the
+// O(D) passes' grid, so their dirty flags apply) pixel by pixel; for a pixel, a thread keeps one d'
+// (the low `shift` bits of its index) and walks d in steps of kBlock >> shift.
 // Dynamic LDS: 8 D doubles + D ints + 5 D bytes.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *__restrict__ phi,
@@ -1572,6 +1578,7 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
                                                           int nseg)
 {
     extern __shared__ double eps_lds[];
+    __shared__ int holders;
     const int D = g.D;
     double *own = eps_lds;            // [4][D]
     double *nbr = own + 4 * D;        // [4][D]: the neighbour's reverse slot
@@ -1579,112 +1586,120 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
     uint8_t *mine = reinterpret_cast<uint8_t *>(support + D);            // [D]
     uint8_t *theirs = mine + D;                                          // [4][D]
     const int tid = threadIdx.x, lane = tid & 63;
-    const long long pix = blockIdx.x;
-    const int i = (int)(pix / g.W), j = (int)(pix % g.W);
-    const int colour = (i + j) & 1, jc = j >> 1, il = i - g.row0 + 1;
-    const bool has[4] = {j > 0, i > 0, j + 1 < g.W, i + 1 < g.H};
-    const int ni[4] = {i, i - 1, i, i + 1}, nj[4] = {j - 1, j, j + 1, j};
-    const long long own_off = (long long)il * g.row_stride + (long long)jc * g.Dpad;
-    uint8_t *alive_t = mask_base(g, alive, colour) + ((long long)(i - g.row0) * g.Wh + jc) * g.Dpad;
-    // the O(D) passes' dirty flags (co_block_dirty), at their granularity
-    const long long flag_at = (long long)(i - g.row0) * nseg + jc / seg_pixels;
-    if (phase == 1 && dirty_prev &&
-        !co_block_dirty(dirty_prev, dirty_cur, flag_at, i - g.row0, jc / seg_pixels, g.Hb, nseg))
+    // grid = (row segments, band rows), the O(D) passes' blocks and their dirty flags
+    // (co_block_dirty); the block takes its segment's pixels one after the other
+    const int seg = blockIdx.x, i = g.row0 + (int)blockIdx.y;
+    const long long flag_at = (long long)blockIdx.y * nseg + seg;
+    if (phase == 1 && dirty_prev && !co_block_dirty(dirty_prev, dirty_cur, flag_at, (int)blockIdx.y, seg, g.Hb, nseg))
         return;
-
-    for (int e = tid; e < 4 * D; e += kBlock) {
-        const int n = e / D, d = e % D;
-        double a = 0., b = 0.;
-        uint8_t m = 0;
-        if (has[n]) {
-            a = (double)phi[g.plane_off[colour][n] + own_off + d];
-            const long long off = (long long)(ni[n] - g.row0 + 1) * g.row_stride + (long long)(nj[n] >> 1) * g.Dpad;
-            b = (double)phi[g.plane_off[1 - colour][n ^ 2] + off + d];
-            if (phase == 1)
-                m = *reinterpret_cast<const volatile uint8_t *>(
-                        mask_base(g, alive, 1 - colour) + ((long long)(ni[n] - g.row0) * g.Wh + (nj[n] >> 1)) * g.Dpad + d) & 1u;
-        }
-        own[e] = a;
-        nbr[e] = b;
-        theirs[e] = m;
-    }
-    __syncthreads();
-    if (phase == 0) {
-        const double limit = mins[pix * 5] + eps;
-        for (int d = tid; d < g.Dpad; d += kBlock) {
-            bool keep = false;
-            if (d < D && d <= j) {
-                double sum = 0.;
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    if (has[n]) sum += own[n * D + d];
-                const double v = (double)cost[colour * g.cost_colour_stride + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d] - sum;
-                keep = v <= limit;
-            }
-            alive_t[d] = keep ? 1 : 0;
-        }
-        return;
-    }
-    for (int d = tid; d < D; d += kBlock) {
-        mine[d] = *reinterpret_cast<const volatile uint8_t *>(alive_t + d) & 1u;
-        support[d] = 0;
-    }
-    __syncthreads();
     const int nd = tid & ((1 << shift) - 1), dstep = kBlock >> shift;
-    const int dmax = j < D - 1 ? j : D - 1;
     const int group_lanes = shift >= 6 ? 64 : (1 << shift);  // lanes of a wavefront that work on the same d
     const unsigned long long group_mask =
         group_lanes == 64 ? ~0ull : (((1ull << group_lanes) - 1ull) << (lane & ~(group_lanes - 1)));
     const bool group_leader = (lane & (group_lanes - 1)) == 0;
-    for (int n = 0; n < 4; ++n) {
-        if (!has[n]) continue;  // uniform over the block
-        const bool nd_ok = nd < D && nd <= nj[n];
-        const double psi = nd < D ? nbr[n * D + nd] : 0.;
-        const bool their_vertex = nd < D && theirs[n * D + nd];
-        const double limit_t = mins[pix * 5 + 1 + n] + eps;
-        const double limit_n = mins[((long long)ni[n] * g.W + nj[n]) * 5 + 1 + (n ^ 2)] + eps;
-        for (int d = tid >> shift; d <= dmax; d += dstep) {
-            if (!mine[d]) continue;  // uniform over the lanes that share d
-            bool ok = nd_ok;
-            if (n == 2 && nd > d + 1) ok = false;
-            if (n == 0 && d > nd + 1) ok = false;
-            if (ok) {
-                const double dist = d > nd ? (double)(d - nd) : (double)(nd - d);
-                const double phi_d = own[n * D + d];
-                const bool a_t = lambda * dist + phi_d + psi <= limit_t;
-                const bool a_n = lambda * dist + psi + phi_d <= limit_n;
-                ok = a_t && (their_vertex || !a_n);
+    bool block_changed = false;
+
+    auto pixel = [&](int j) {
+        const long long pix = (long long)i * g.W + j;
+        const int colour = (i + j) & 1, jc = j >> 1, il = i - g.row0 + 1;
+        const bool has[4] = {j > 0, i > 0, j + 1 < g.W, i + 1 < g.H};
+        const int ni[4] = {i, i - 1, i, i + 1}, nj[4] = {j - 1, j, j + 1, j};
+        const long long own_off = (long long)il * g.row_stride + (long long)jc * g.Dpad;
+        uint8_t *alive_t = mask_base(g, alive, colour) + ((long long)(i - g.row0) * g.Wh + jc) * g.Dpad;
+        __syncthreads();  // the previous pixel's LDS is done with
+        for (int e = tid; e < 4 * D; e += kBlock) {
+            const int n = e / D, d = e % D;
+            double a = 0., b = 0.;
+            uint8_t m = 0;
+            if (has[n]) {
+                a = (double)phi[g.plane_off[colour][n] + own_off + d];
+                const long long off = (long long)(ni[n] - g.row0 + 1) * g.row_stride + (long long)(nj[n] >> 1) * g.Dpad;
+                b = (double)phi[g.plane_off[1 - colour][n ^ 2] + off + d];
+                if (phase == 1)
+                    m = *reinterpret_cast<const volatile uint8_t *>(
+                            mask_base(g, alive, 1 - colour) + ((long long)(ni[n] - g.row0) * g.Wh + (nj[n] >> 1)) * g.Dpad + d) & 1u;
             }
-            // one LDS atomic per group of lanes that share d, not one per lane
-            const unsigned long long found = __ballot(ok) & group_mask;
-            if (found && group_leader) atomicOr(&support[d], 1 << n);
+            own[e] = a;
+            nbr[e] = b;
+            theirs[e] = m;
         }
-    }
-    __syncthreads();
-    const int need = (has[0] ? 1 : 0) | (has[1] ? 2 : 0) | (has[2] ? 4 : 0) | (has[3] ? 8 : 0);
-    bool died = false, left = false;
-    for (int d = tid; d < D; d += kBlock) {
-        if (!mine[d]) continue;
-        if ((support[d] & need) != need) {
-            alive_t[d] = 0;
-            died = true;
-        } else {
-            left = true;
+        if (tid == 0) holders = 0;
+        __syncthreads();
+        if (phase == 0) {
+            const double limit = mins[pix * 5] + eps;
+            for (int d = tid; d < g.Dpad; d += kBlock) {
+                bool keep = false;
+                if (d < D && d <= j) {
+                    double sum = 0.;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        if (has[n]) sum += own[n * D + d];
+                    const double v = (double)cost[colour * g.cost_colour_stride + ((long long)(il - 1) * g.Wh + jc) * g.Dpad + d] - sum;
+                    keep = v <= limit;
+                }
+                alive_t[d] = keep ? 1 : 0;
+            }
+            return;
         }
-    }
-    died = __any(died);
-    left = __any(left);
-    if (lane == 0 && died) {
+        for (int d = tid; d < D; d += kBlock) {
+            mine[d] = *reinterpret_cast<const volatile uint8_t *>(alive_t + d) & 1u;
+            support[d] = 0;
+        }
+        __syncthreads();
+        const int dmax = j < D - 1 ? j : D - 1;
+        for (int n = 0; n < 4; ++n) {
+            if (!has[n]) continue;  // uniform over the block
+            const bool nd_ok = nd < D && nd <= nj[n];
+            const double psi = nd < D ? nbr[n * D + nd] : 0.;
+            const bool their_vertex = nd < D && theirs[n * D + nd];
+            const double limit_t = mins[pix * 5 + 1 + n] + eps;
+            const double limit_n = mins[((long long)ni[n] * g.W + nj[n]) * 5 + 1 + (n ^ 2)] + eps;
+            for (int d = tid >> shift; d <= dmax; d += dstep) {
+                if (!mine[d]) continue;  // uniform over the lanes that share d
+                bool ok = nd_ok;
+                if (n == 2 && nd > d + 1) ok = false;
+                if (n == 0 && d > nd + 1) ok = false;
+                if (ok) {
+                    const double dist = d > nd ? (double)(d - nd) : (double)(nd - d);
+                    const double phi_d = own[n * D + d];
+                    const bool a_t = lambda * dist + phi_d + psi <= limit_t;
+                    const bool a_n = lambda * dist + psi + phi_d <= limit_n;
+                    ok = a_t && (their_vertex || !a_n);
+                }
+                // one LDS atomic per group of lanes that share d, not one per lane
+                const unsigned long long found = __ballot(ok) & group_mask;
+                if (found && group_leader) atomicOr(&support[d], 1 << n);
+            }
+        }
+        __syncthreads();
+        const int need = (has[0] ? 1 : 0) | (has[1] ? 2 : 0) | (has[2] ? 4 : 0) | (has[3] ? 8 : 0);
+        bool died = false, left = false;
+        for (int d = tid; d < D; d += kBlock) {
+            if (!mine[d]) continue;
+            if ((support[d] & need) != need) {
+                alive_t[d] = 0;
+                died = true;
+            } else {
+                left = true;
+            }
+        }
+        if (__any(died)) block_changed = true;
+        // "the pixel has no vertex left" needs all wavefronts: count those that still hold one
+        const bool wave_holds = __any(left);
+        if (lane == 0 && wave_holds) atomicAdd(&holders, 1);
+        __syncthreads();
+        if (tid == 0 && holders == 0) atomicOr(changed + 1, 1);
+    };
+
+    for (int colour = 0; colour < 2; ++colour)
+        for (int q = 0; q < seg_pixels; ++q) {
+            const int j = 2 * (seg * seg_pixels + q) + ((i + colour) & 1);
+            if (j < g.W) pixel(j);  // uniform over the block
+        }
+    if (block_changed && lane == 0) {
         atomicOr(changed, 1);
         if (dirty_cur) dirty_cur[flag_at] = 1;
     }
-    // "the pixel has no vertex left" needs all wavefronts: count those that still hold one
-    __shared__ int holders;
-    if (tid == 0) holders = 0;
-    __syncthreads();
-    if (lane == 0 && left) atomicAdd(&holders, 1);
-    __syncthreads();
-    if (tid == 0 && holders == 0) atomicOr(changed + 1, 1);
 }
 
 // ---- stage 1: cost volume --------------------------------------------------------------
