@@ -108,6 +108,7 @@ struct ds_handle {
     uint8_t *co_dirty = nullptr;                      // [2][Hb][grid_x]: blocks that deleted something, last pass / this pass
     int co_prev = 0;                                  // which half of co_dirty the next pass reads
     bool co_dirty_all = true;                         // masks changed outside the whole-band passes: every block is due
+    int co_passes_done = 0;                           // whole-band relaxation passes since the masks were made
     long long *co_state = nullptr;                    // co_fix_kernel's report, [2]
     double co_epsilon = 0.0;
     long long raster_pending = 0;                     // iterations asked for by ds_iterate_raster_async, not yet queued
@@ -1851,6 +1852,7 @@ static int co_prepare(ds_handle *h, const ds::Geometry &g, double epsilon)
     h->co_epsilon = epsilon;
     h->co_fixed = false;
     h->co_dirty_all = true;  // the first pass looks at every pixel
+    h->co_passes_done = 0;
     HIPCHK(h, hipMemsetAsync(h->co_alive, 0, mask_bytes, h->stream));
     // Halo rows start all-alive: until the neighbouring band's rows arrive they must not
     // take support away (deletions cannot be undone; a late deletion only costs a pass).
@@ -1913,7 +1915,10 @@ static int co_dirty_flags(ds_handle *h, const uint8_t **prev, uint8_t **cur)
         if (std::strcmp(e, "off") == 0) return DS_OK;
     const size_t half = (size_t)g.Hb * h->grid_x;
     uint8_t *p = h->co_dirty + (size_t)h->co_prev * half, *c = h->co_dirty + (size_t)(1 - h->co_prev) * half;
-    if (h->co_dirty_all) HIPCHK(h, hipMemsetAsync(p, 1, half, h->stream));
+    if (h->co_dirty_all) {
+        HIPCHK(h, hipMemsetAsync(p, 1, half, h->stream));
+        h->co_passes_done = 0;  // every block has work again
+    }
     HIPCHK(h, hipMemsetAsync(c, 0, half, h->stream));
     h->co_dirty_all = false;
     h->co_prev = 1 - h->co_prev;  // what this pass writes is what the next one reads
@@ -1946,9 +1951,11 @@ static int co_launch_pass(ds_handle *h, int radius = -1, int wi = 0, int wj = 0)
     uint8_t *dirty_cur = nullptr;
     if (radius >= 0) h->co_dirty_all = true;  // a windowed pass keeps no flags: the next whole pass looks everywhere
     else if (co_dirty_flags(h, &dirty_prev, &dirty_cur) != DS_OK) return DS_ERR_HIP;
-    // with dirty flags most blocks of a late pass return at once: fewer, longer blocks then (eight
-    // segments each, as long as that leaves thousands of blocks)
-    const int per_block = dirty_prev && (long long)segs * rows >= 65536 ? 8 : 1;
+    // with dirty flags most blocks of a late pass return at once: fewer, longer blocks then (32
+    // segments each, their flags looked up by 32 lanes at once); the first passes, where every block
+    // has work, keep one segment per block
+    const int per_block = dirty_prev && h->co_passes_done >= 2 && (long long)segs * rows >= 65536 ? 32 : 1;
+    if (radius < 0) ++h->co_passes_done;
     const dim3 grid((segs + per_block - 1) / per_block, rows), block(ds::kBlock);
     for (int colour = 0; colour < 2; ++colour) {
         int rc = dispatch(h, [&](auto t, auto lpp) -> int {

@@ -1103,12 +1103,29 @@ __global__ __launch_bounds__(kBlock) void co_relax_kernel(Geometry g, const T *_
     // whose four neighbouring blocks (same rows of the segments beside it, same segment of the rows
     // above and below) changed nothing in the previous pass, nor yet in this one, has nothing to do.
     // Deletions travel one or two pixels per pass, so late passes are thin fronts.
-    // A block takes segs_per_block consecutive segments of its row, one after the other: late passes
-    // are launches of blocks that return, and cost what launching them costs.
-    for (int seg = seg_first + (int)blockIdx.x * segs_per_block;
-         seg < seg_first + ((int)blockIdx.x + 1) * segs_per_block && seg < seg_end; ++seg) {
+    // A block takes segs_per_block (<= 64) consecutive segments of its row.  Which of them are due is
+    // looked up by as many lanes at once (one round trip to the flags, not one per segment: in a late
+    // pass nearly every block returns here, and the pass costs what those round trips cost).
+    __shared__ unsigned long long due_lds;
+    const int seg_block = seg_first + (int)blockIdx.x * segs_per_block;
+    unsigned long long due;
+    if (dirty_prev) {
+        if (wave == 0) {
+            const int seg = seg_block + lane;
+            const bool mine_due = lane < segs_per_block && seg < seg_end &&
+                                  co_block_dirty(dirty_prev, dirty_cur, (long long)(i - g.row0) * nseg + seg, i - g.row0, seg, g.Hb, nseg);
+            const unsigned long long ballot = __ballot(mine_due);
+            if (lane == 0) due_lds = ballot;
+        }
+        __syncthreads();
+        due = due_lds;
+    } else {
+        const int count = seg_end - seg_block < segs_per_block ? seg_end - seg_block : segs_per_block;
+        due = count >= 64 ? ~0ull : ((1ull << (count > 0 ? count : 0)) - 1ull);
+    }
+    for (; due; due &= due - 1ull) {
+    const int seg = seg_block + __builtin_ctzll(due);
     const long long flag_at = (long long)(i - g.row0) * nseg + seg;
-    if (dirty_prev && !co_block_dirty(dirty_prev, dirty_cur, flag_at, i - g.row0, seg, g.Hb, nseg)) continue;
     T lam[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) lam[k] = lambda * (T)(d0 + k);
