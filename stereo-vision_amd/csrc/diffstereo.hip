@@ -1954,7 +1954,7 @@ static int co_launch_pass(ds_handle *h, int radius = -1, int wi = 0, int wj = 0)
     // with dirty flags most blocks of a late pass return at once: fewer, longer blocks then (32
     // segments each, their flags looked up by 32 lanes at once); the first passes, where every block
     // has work, keep one segment per block
-    const int per_block = dirty_prev && h->co_passes_done >= 2 && (long long)segs * rows >= 65536 ? 32 : 1;
+    const int per_block = dirty_prev && h->co_passes_done >= 2 && (long long)segs * rows >= 1024 ? 32 : 1;
     if (radius < 0) ++h->co_passes_done;
     const dim3 grid((segs + per_block - 1) / per_block, rows), block(ds::kBlock);
     for (int colour = 0; colour < 2; ++colour) {

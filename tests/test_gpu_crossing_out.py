@@ -217,3 +217,32 @@ def test_exact_crossing_out_leaves_the_state_other_entry_points_expect():
         band.crossing_out(2.0, exact=True)
     band.close()
     g.close()
+
+
+@pytest.mark.parametrize("H,W,D,dtype,iters", [(128, 1024, 4, "f64", 3), (96, 1200, 8, "f32", 2), (70, 900, 12, "f64", 0),
+                                               (128, 1024, 4, "f64", 12)])
+def test_skipping_blocks_with_nothing_to_do_changes_no_mask(monkeypatch, H, W, D, dtype, iters):
+    """Relaxation passes skip blocks whose neighbourhood deleted nothing in the last pass, and from
+    the third pass on a block takes 32 row segments.  With DS_CO_DIRTY=off every block runs in every
+    pass: the same masks, the same labels, both with the O(D) comparisons and the reference's -- at
+    the smallest epsilon that leaves a graph, just below it and well above it, where relaxations are long."""
+    left, right = random_pair(H, W, seed=H + W + D)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype=dtype)
+    if iters == 0:
+        g.set_phi(random_phi(H, W, D, dtype, seed=5))
+    else:
+        g.iterate(iters)
+    star = g.epsilon_search(exact=True)
+    longest = 0
+    for eps in (star, star * 0.999, star * 1.3, star * 2.0):
+        for exact in (False, True):
+            got = g.crossing_out(eps, with_mask=True, exact=exact)
+            monkeypatch.setenv("DS_CO_DIRTY", "off")
+            want = g.crossing_out(eps, with_mask=True, exact=exact)
+            monkeypatch.delenv("DS_CO_DIRTY")
+            assert np.array_equal(got["alive"], want["alive"]), (eps, exact)
+            assert np.array_equal(got["labels"], want["labels"]) and got["not_empty"] == want["not_empty"]
+            longest = max(longest, got["passes"])
+    assert g.crossing_out(star, exact=True)["not_empty"] and not g.crossing_out(star * 0.999, exact=True)["not_empty"]
+    print("smallest epsilon with a graph %g, longest relaxation %d passes" % (star, longest))
+    g.close()
