@@ -109,6 +109,7 @@ struct ds_handle {
     int co_prev = 0;                                  // which half of co_dirty the next pass reads
     bool co_dirty_all = true;                         // masks changed outside the whole-band passes: every block is due
     int co_passes_done = 0;                           // whole-band relaxation passes since the masks were made
+    int *co_version = nullptr;                        // [2][H][W], ds_crossing_out_exact: passes in which a pixel lost labels / what it saw last
     long long *co_state = nullptr;                    // co_fix_kernel's report, [2]
     double co_epsilon = 0.0;
     long long raster_pending = 0;                     // iterations asked for by ds_iterate_raster_async, not yet queued
@@ -298,6 +299,7 @@ void release(ds_handle *h)
     (void)hipFree(h->co_host_order);
     (void)hipFree(h->co_flags);
     (void)hipFree(h->co_dirty);
+    (void)hipFree(h->co_version);
     (void)hipFree(h->co_state);
     (void)hipFree(h->eps_buf[0]);
     (void)hipFree(h->eps_buf[1]);
@@ -2338,19 +2340,35 @@ static int crossing_out_exact(ds_handle *h, double epsilon, const double *mins, 
     int shift = 0;
     while ((1 << shift) < g.D) ++shift;
     const size_t lds = (size_t)g.D * (8 * sizeof(double) + sizeof(int) + 5) + 8;
-    const dim3 grid(h->grid_x, g.Hb);
+    // per pixel: in how many passes it lost labels, and the sum of its neighbours' counts when it was
+    // last looked at (co_exact_kernel looks at a pixel again only when the two differ)
+    const size_t pixels = (size_t)g.H * g.W;
+    if (!h->co_version) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->co_version), 2 * pixels * sizeof(int));
+        if (e != hipSuccess) return fail_hip(h, "hipMalloc (crossing-out versions)", e);
+    }
+    HIPCHK(h, hipMemsetAsync(h->co_version, 0, pixels * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->co_version + pixels, 0xff, pixels * sizeof(int), h->stream));
+    const char *dirty_env = std::getenv("DS_CO_DIRTY");
+    int *version = dirty_env && std::strcmp(dirty_env, "off") == 0 ? nullptr : h->co_version;
+    int *seen = version ? version + pixels : nullptr;
+    int passes_done = 0;
     auto launch = [&](int phase) -> int {
         const uint8_t *dirty_prev = nullptr;
         uint8_t *dirty_cur = nullptr;
         if (phase == 1 && co_dirty_flags(h, &dirty_prev, &dirty_cur) != DS_OK) return DS_ERR_HIP;
+        // from the third pass on most segments have nothing to do: 32 of them per block then
+        const int per_block = phase == 1 && dirty_prev && passes_done >= 2 ? 32 : 1;
+        if (phase == 1) ++passes_done;
+        const dim3 grid((h->grid_x + per_block - 1) / per_block, g.Hb);
         if (h->dtype == DS_F64)
             hipLaunchKernelGGL(ds::co_exact_kernel<double>, grid, block, lds, h->stream, g, static_cast<const double *>(h->phi),
                                h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase, dirty_prev,
-                               dirty_cur, h->seg_pixels, h->grid_x);
+                               dirty_cur, h->seg_pixels, h->grid_x, version, seen, per_block);
         else
             hipLaunchKernelGGL(ds::co_exact_kernel<float>, grid, block, lds, h->stream, g, static_cast<const float *>(h->phi),
                                h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase, dirty_prev,
-                               dirty_cur, h->seg_pixels, h->grid_x);
+                               dirty_cur, h->seg_pixels, h->grid_x, version, seen, per_block);
         HIPCHK(h, hipGetLastError());
         return DS_OK;
     };

@@ -1592,10 +1592,12 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
                                                           int shift, const double *__restrict__ mins, uint8_t *alive,
                                                           int *__restrict__ changed, int phase,
                                                           const uint8_t *dirty_prev, uint8_t *dirty_cur, int seg_pixels,
-                                                          int nseg)
+                                                          int nseg, int *version, int *seen, int segs_per_block)
 {
     extern __shared__ double eps_lds[];
-    __shared__ int holders;
+    __shared__ int holders, pixel_died;
+    __shared__ unsigned long long due_lds, due_segments_lds;
+    __shared__ int sum_lds[64];
     const int D = g.D;
     double *own = eps_lds;            // [4][D]
     double *nbr = own + 4 * D;        // [4][D]: the neighbour's reverse slot
@@ -1603,20 +1605,67 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
     uint8_t *mine = reinterpret_cast<uint8_t *>(support + D);            // [D]
     uint8_t *theirs = mine + D;                                          // [4][D]
     const int tid = threadIdx.x, lane = tid & 63;
-    // grid = (row segments, band rows), the O(D) passes' blocks and their dirty flags
-    // (co_block_dirty); the block takes its segment's pixels one after the other
-    const int seg = blockIdx.x, i = g.row0 + (int)blockIdx.y;
-    const long long flag_at = (long long)blockIdx.y * nseg + seg;
-    if (phase == 1 && dirty_prev && !co_block_dirty(dirty_prev, dirty_cur, flag_at, (int)blockIdx.y, seg, g.Hb, nseg))
-        return;
+    // grid = (row segments / segs_per_block, band rows): the O(D) passes' segments and their dirty
+    // flags (co_block_dirty).  Which of the block's segments are due is looked up by as many lanes
+    // at once (co_relax_kernel does the same); a due segment's pixels are taken one after the other.
+    const int i = g.row0 + (int)blockIdx.y;
+    const int seg_block = (int)blockIdx.x * segs_per_block;
+    unsigned long long due_segments;
+    if (phase == 1 && dirty_prev) {
+        if (tid < 64) {
+            const int sg = seg_block + tid;
+            const bool mine_due = tid < segs_per_block && sg < nseg &&
+                                  co_block_dirty(dirty_prev, dirty_cur, (long long)blockIdx.y * nseg + sg, (int)blockIdx.y, sg, g.Hb, nseg);
+            const unsigned long long ballot = __ballot(mine_due);
+            if (tid == 0) due_segments_lds = ballot;
+        }
+        __syncthreads();
+        due_segments = due_segments_lds;
+    } else {
+        const int count = nseg - seg_block < segs_per_block ? nseg - seg_block : segs_per_block;
+        due_segments = count >= 64 ? ~0ull : ((1ull << (count > 0 ? count : 0)) - 1ull);
+    }
     const int nd = tid & ((1 << shift) - 1), dstep = kBlock >> shift;
     const int group_lanes = shift >= 6 ? 64 : (1 << shift);  // lanes of a wavefront that work on the same d
     const unsigned long long group_mask =
         group_lanes == 64 ? ~0ull : (((1ull << group_lanes) - 1ull) << (lane & ~(group_lanes - 1)));
     const bool group_leader = (lane & (group_lanes - 1)) == 0;
+    for (; due_segments; due_segments &= due_segments - 1ull) {
+    const int seg = seg_block + __builtin_ctzll(due_segments);
+    const long long flag_at = (long long)blockIdx.y * nseg + seg;
     bool block_changed = false;
+    __syncthreads();  // the previous segment's shared words are done with
+    // Which of the segment's pixels are due: version[pixel] counts the passes in which the pixel lost
+    // labels, seen[pixel] is the sum of its neighbours' versions when it was last looked at; equal
+    // sums mean that no neighbour's mask has changed since, and neither can the pixel's answer.
+    // One lane per pixel looks that up (segments of up to 64 pixels; larger ones look at every pixel).
+    const bool tracked = phase == 1 && version && 2 * seg_pixels <= 64;
+    unsigned long long due = ~0ull;
+    if (tracked) {
+        if (tid < 64) {
+            const int colour = tid / seg_pixels, q = tid % seg_pixels;
+            const int j = 2 * (seg * seg_pixels + q) + ((i + colour) & 1);
+            int sum = 0;
+            bool mine_due = false;
+            if (tid < 2 * seg_pixels && j < g.W) {
+                const volatile int *v = version;
+                const long long pix = (long long)i * g.W + j;
+                if (j > 0) sum += v[pix - 1];
+                if (i > 0) sum += v[pix - g.W];
+                if (j + 1 < g.W) sum += v[pix + 1];
+                if (i + 1 < g.H) sum += v[pix + g.W];
+                mine_due = sum != seen[pix];
+            }
+            sum_lds[tid] = sum;
+            const unsigned long long ballot = __ballot(mine_due);
+            if (tid == 0) due_lds = ballot;
+        }
+        __syncthreads();
+        due = due_lds;
+        if (due == 0ull) continue;
+    }
 
-    auto pixel = [&](int j) {
+    auto pixel = [&](int j, int slot) {
         const long long pix = (long long)i * g.W + j;
         const int colour = (i + j) & 1, jc = j >> 1, il = i - g.row0 + 1;
         const bool has[4] = {j > 0, i > 0, j + 1 < g.W, i + 1 < g.H};
@@ -1640,7 +1689,10 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
             nbr[e] = b;
             theirs[e] = m;
         }
-        if (tid == 0) holders = 0;
+        if (tid == 0) {
+            holders = 0;
+            pixel_died = 0;
+        }
         __syncthreads();
         if (phase == 0) {
             const double limit = mins[pix * 5] + eps;
@@ -1700,22 +1752,35 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
                 left = true;
             }
         }
-        if (__any(died)) block_changed = true;
+        const bool wave_died = __any(died);
+        if (wave_died) block_changed = true;
         // "the pixel has no vertex left" needs all wavefronts: count those that still hold one
         const bool wave_holds = __any(left);
         if (lane == 0 && wave_holds) atomicAdd(&holders, 1);
+        if (lane == 0 && wave_died) pixel_died = 1;
         __syncthreads();
-        if (tid == 0 && holders == 0) atomicOr(changed + 1, 1);
+        if (tid == 0) {
+            if (holders == 0) atomicOr(changed + 1, 1);
+            if (tracked) {
+                // the sum was read before the masks were: a neighbour that changed in between makes
+                // the pixel due once more than needed, never once less
+                seen[pix] = sum_lds[slot];
+                if (pixel_died) version[pix] = version[pix] + 1;
+            }
+        }
     };
 
     for (int colour = 0; colour < 2; ++colour)
         for (int q = 0; q < seg_pixels; ++q) {
+            const int slot = colour * seg_pixels + q;
+            if (tracked && !((due >> slot) & 1ull)) continue;
             const int j = 2 * (seg * seg_pixels + q) + ((i + colour) & 1);
-            if (j < g.W) pixel(j);  // uniform over the block
+            if (j < g.W) pixel(j, slot);  // uniform over the block
         }
     if (block_changed && lane == 0) {
         atomicOr(changed, 1);
         if (dirty_cur) dirty_cur[flag_at] = 1;
+    }
     }
 }
 
