@@ -85,7 +85,9 @@ def _gloo_worker(rank, world, port, dtype, D, H, W, out, halo="one-row"):
                                                (3, "f64", 140, 29, 75), (2, "f64", 64, 17, 130), (3, "f32", 100, 40, 33),
                                                (3, "f32", 64, 23, 70), (4, "f64", 40, 33, 52),
                                                (3, "f32", 64, 60, 330), (2, "f32", 128, 41, 420), (2, "f32", 256, 36, 330),
-                                               (3, "f32", 64, 50, 330)])
+                                               (3, "f32", 64, 50, 330),
+                                               # D that is not a multiple of 4, D = 40 in f64: bands step by two as well
+                                               (2, "f32", 41, 40, 500), (2, "f64", 130, 36, 200), (3, "f64", 40, 60, 300)])
 def test_ranks_sharing_one_gpu(world, dtype, D, H, W):
     """H = 13: bands of 4-7 rows sweep colour by colour; H = 29 and more: bands of 8 rows or more
     run the fused kernel in their interior; H = 23 over three ranks (8, 8, 7 rows) and H = 33 over
@@ -102,16 +104,16 @@ def test_ranks_sharing_one_gpu(world, dtype, D, H, W):
     # has every rank on it, next to bands that are not in the other cases
     steps = [out[rank][3] for rank in range(world)]
     assert all(k in (0, 4) for k in steps)
-    if W >= 330 and dtype == "f32":
-        assert steps == [4] * world, steps
-    elif dtype == "f64" or D not in (64, 128, 256):
-        assert steps == [0] * world, steps
+    if (W >= 330 and dtype == "f32") or (dtype, D, H, W) in (("f32", 41, 40, 500), ("f64", 130, 36, 200), ("f64", 40, 60, 300)):
+        assert steps == [4] * world, steps   # bands of 14 rows or more with room for a strip: any D, both precisions
+    elif H < 28 * world // 2 and W < 100:
+        assert steps == [0] * world, steps   # bands under 14 rows step by one
     # the narrow f32 cases with D = 64 / 256: whichever bands have eight interior rows and room for
     # one strip step by two beside neighbours that do not (29 x 75 x 256: the 15-row band only)
 
 
 @pytest.mark.parametrize("world,D,H,W", [(3, 64, 60, 330), (2, 128, 41, 420), (2, 256, 36, 330), (3, 64, 50, 330),
-                                         (2, 40, 40, 500), (4, 256, 70, 330)])
+                                         (2, 40, 40, 500), (4, 256, 70, 330), (2, 41, 40, 500), (2, 203, 44, 330)])
 def test_deep_halo_bands(world, D, H, W):
     """DS_BAND_HALO=deep: bands of 16 rows or more keep four rows of each neighbour and exchange once
     per two-iteration step.  Same bar: every band's potentials, energy, labels, cost and crossing-out
