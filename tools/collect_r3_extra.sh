@@ -1,4 +1,4 @@
-# Round 3, second block: the HBM counters again (minimum per launch: the ordinary launch, without the
+# Second block of measurements: the HBM counters again (minimum per launch: the ordinary launch, without the
 # first colour's store of a call's last step), the f64 two-iteration probe, the other workloads,
 # rehearsals of the N > 1 line in both halo modes.
 set -e
