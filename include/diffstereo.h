@@ -208,8 +208,9 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
  * so a copy whose twin was never set outlives that vertex -- reproduced.  Result: the reference's
  * vertex masks for ANY epsilon, including one that is itself a gap of the graph (the candidates of
  * epsilon search), where ds_crossing_out may fall on the other side of a threshold.  Price:
- * O(D^2) per pixel and pass instead of O(D) (1920 x 1080 x 128: 0.1 s per pass), and H*W*5
- * doubles.  Whole-image handles.  ds_find_best_labeling may follow. */
+ * O(D^2) per pixel looked at instead of O(D) (1920 x 1080 x 128: 0.1 s for a pass over every
+ * pixel; later passes look only at pixels with a neighbour whose mask has changed), and H*W*5
+ * doubles + 2*H*W ints.  Whole-image handles.  ds_find_best_labeling may follow. */
 int ds_crossing_out_exact(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
                           int *not_empty, int *passes);
 
@@ -266,10 +267,13 @@ int ds_dedup_gaps(const double *sorted, size_t n, double tolerance, int largest_
  * array's last element).  No array: the crossing-out is asked about real numbers until the
  * interval that holds the answer is a few candidates wide (the predicate only changes at gaps),
  * then the gaps above the interval's lower end are produced one at a time (ds_epsilon_next)
- * and tried in ascending order.  Memory: H*W*5 doubles.
+ * and tried in ascending order.  Memory: H*W*5 doubles beside the crossing-out's own state.
  * exact = 1: the predicate is ds_crossing_out_exact (the reference's comparisons bit for bit;
- * f32 handles allowed, their potentials are widened); exact = 0: ds_crossing_out (O(D) per
- * pixel and pass, the rounding described there; f64 handles only).
+ * f32 handles allowed, their potentials are widened).  On f64 handles ds_crossing_out still does
+ * the halving first; the interval it ends with is widened by a bound on its rounding, confirmed
+ * at both ends with the reference's comparisons, and they finish the search inside it.
+ * exact = 0: ds_crossing_out alone (O(D) per pixel and pass, the rounding described there: the
+ * result may be a neighbour, in the sorted array, of the reference's; f64 handles only).
  * With tolerance 0 the reference's array is the set of distinct gaps and the result is the
  * reference's; its tolerance > 0 thins the array out to one value per run of values within the
  * tolerance, which needs the whole sorted array and is not reproduced (the result here is then
