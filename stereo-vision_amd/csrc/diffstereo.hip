@@ -1103,7 +1103,22 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
         // 16/15 of phi); f64 (178 VGPRs, two wavefronts per SIMD): 8, 6.37 ms on a 540-row band of
         // 8K x 256 against 6.80 with 4.
         const char *e = std::getenv("DS_FUSED");
-        const bool off = e && std::strcmp(e, "off") == 0;
+        bool off = e && std::strcmp(e, "off") == 0;
+        // Potentials that fit the GPU's 256 MiB last-level cache (all eight planes: the reference's own
+        // working scale, 400 x 400 x 40 in f64, is 205 MB) are iterated by half-sweeps: their planes
+        // then come from that cache at several times HBM's rate and a half-sweep is thousands of small
+        // blocks, where the fused kernels' few long blocks and the launches for their frame leave most
+        // of the GPU idle.  Measured, ms per iteration, fused / half-sweeps: 400 x 400 x 40 f32
+        // 0.090 / 0.038, f64 0.090 / 0.067; 300 x 200 x 40 f64 0.088 / 0.029; beyond the cache the
+        // fused kernels win: 512 x 512 x 40 f64 0.112 / 0.147, 800 x 600 x 40 f32 0.101 / 0.116.
+        // Same bits either way.  DS_CACHE_RESIDENT=fused keeps the fused kernels (for checking them
+        // on small images).
+        {
+            const char *small = std::getenv("DS_CACHE_RESIDENT");
+            const bool keep = small && std::strcmp(small, "fused") == 0;
+            const size_t eight_planes = (size_t)(8 * h->plane_elems) * (dtype == DS_F64 ? 8 : 4);
+            if (!keep && eight_planes <= (256ull << 20)) off = true;
+        }
         h->fused_waves = off ? 0 : (dtype == DS_F64 ? 8 : 16);
         if (const char *w = std::getenv("DS_FUSED_WAVES"))  // tuning knob
             if (h->fused_waves && (std::atoi(w) == 4 || std::atoi(w) == 8 || (std::atoi(w) == 16 && dtype != DS_F64)))
