@@ -95,7 +95,10 @@ int ds_get_cost(ds_handle *h, uint8_t *out);
  * colour's potentials on chip (they are a function of the second colour's) and moves only
  * the second colour's planes; the call's last launch stores the first colour's planes as well,
  * so every other entry point sees the state 2 n_iters half-sweeps leave.  Same bits as the
- * half-sweeps; DS_FUSED=off at ds_create disables it. */
+ * half-sweeps; DS_FUSED=off at ds_create disables it.  Handles whose potentials fit the GPU's
+ * 256 MiB last-level cache (eight planes of rows * ceil(W/2) * D elements: the reference's own
+ * 400 x 400 x 40 images) are iterated by the half-sweeps by default, which are faster there;
+ * DS_CACHE_RESIDENT=fused at ds_create keeps the fused kernels for them. */
 int ds_iterate(ds_handle *h, int n_iters);
 
 /* Whole iterations on a row band (no counterpart in the reference, which has one process).  The fused kernel recomputes the first colour's rows i-1..i+1 for every row i
