@@ -374,8 +374,17 @@ int exchange_deep(ds_handle *h, const long long *planes, hipStream_t stream)
     if (h->up < 0 && h->down < 0) return DS_OK;
     const ds::Geometry &g = h->g;
     const int o0 = own_begin(h), o1 = own_end(h);
-    float *base = static_cast<float *>(h->phi), *stage = static_cast<float *>(h->deep_stage);
-    float *stage_recv = stage + 32 * g.row_stride;
+    char *stage = static_cast<char *>(h->deep_stage);
+    char *stage_recv = stage + (size_t)(32 * g.row_stride) * h->elem;
+    auto rows_kernel = [&](const ds::HaloRows &rows, void *buffer, int pack) {
+        const dim3 grid(64, 8), block(ds::kBlock);
+        if (h->dtype == DS_F64)
+            hipLaunchKernelGGL(ds::halo_rows_kernel<double>, grid, block, 0, stream, static_cast<double *>(h->phi), rows,
+                               g.row_stride, static_cast<double *>(buffer), pack);
+        else
+            hipLaunchKernelGGL(ds::halo_rows_kernel<float>, grid, block, 0, stream, static_cast<float *>(h->phi), rows,
+                               g.row_stride, static_cast<float *>(buffer), pack);
+    };
     // the four rows of every slot's plane into one buffer per neighbour, that buffer in one
     // transfer, and out again on the other side (rows as rows of the stored planes: halo row = 0)
     ds::HaloRows out{}, in{};
@@ -384,8 +393,7 @@ int exchange_deep(ds_handle *h, const long long *planes, hipStream_t stream)
     out.row[1] = h->down >= 0 ? o1 - 4 - g.row0 + 1 : -1;
     in.row[0] = h->up >= 0 ? o0 - 4 - g.row0 + 1 : -1;
     in.row[1] = h->down >= 0 ? o1 - g.row0 + 1 : -1;
-    const dim3 grid(64, 8), block(ds::kBlock);
-    hipLaunchKernelGGL(ds::halo_rows_kernel<float>, grid, block, 0, stream, base, out, g.row_stride, stage, 1);
+    rows_kernel(out, stage, 1);
     HIPCHK(h, hipGetLastError());
     int peers[2], n = 0;
     void *send[2], *recv[2];
@@ -394,14 +402,14 @@ int exchange_deep(ds_handle *h, const long long *planes, hipStream_t stream)
         const int peer = side == 0 ? h->up : h->down;
         if (peer < 0) continue;
         peers[n] = peer;
-        send[n] = stage + (long long)side * 16 * g.row_stride;
-        recv[n] = stage_recv + (long long)side * 16 * g.row_stride;
+        send[n] = stage + (size_t)((long long)side * 16 * g.row_stride) * h->elem;
+        recv[n] = stage_recv + (size_t)((long long)side * 16 * g.row_stride) * h->elem;
         bytes[n] = (size_t)(16 * g.row_stride) * h->elem;
         ++n;
     }
     if (h->transport.exchange(h->transport.ctx, n, peers, send, recv, bytes, stream) != 0)
         return transport_fail(h, "the deep halo exchange");
-    hipLaunchKernelGGL(ds::halo_rows_kernel<float>, grid, block, 0, stream, base, in, g.row_stride, stage_recv, 0);
+    rows_kernel(in, stage_recv, 0);
     HIPCHK(h, hipGetLastError());
     return DS_OK;
 }
@@ -650,7 +658,7 @@ int ds_band_attach(ds_handle *h, const ds_transport *t, int up_rank, int down_ra
         if (lo != hi) {
             h->attached = false;
             return fail(h, DS_ERR_STATE,
-                        "the bands disagree on DS_BAND_HALO=deep: every band must be created with it, be an f32 band of 16 "
+                        "the bands disagree on DS_BAND_HALO=deep: every band must be created with it, be a band of 16 "
                         "rows or more, four rows or more away from the image's other edge, and have an interior for the "
                         "two-iteration kernel");
         }

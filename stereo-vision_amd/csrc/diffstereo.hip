@@ -1085,7 +1085,7 @@ int create(const uint8_t *left, const uint8_t *right, int H, int W, int D, doubl
     {
         const char *mode = std::getenv("DS_BAND_HALO");
         const bool band = row_begin > 0 || row_end < H;
-        h->deep = mode && std::strcmp(mode, "deep") == 0 && band && dtype == DS_F32 &&
+        h->deep = mode && std::strcmp(mode, "deep") == 0 && band &&
                   (row_begin == 0 || row_begin >= 4) && (row_end == H || H - row_end >= 4) && row_end - row_begin >= 16;
     }
     auto set_rows = [&]() {

@@ -112,16 +112,18 @@ def test_ranks_sharing_one_gpu(world, dtype, D, H, W):
     # one strip step by two beside neighbours that do not (29 x 75 x 256: the 15-row band only)
 
 
-@pytest.mark.parametrize("world,D,H,W", [(3, 64, 60, 330), (2, 128, 41, 420), (2, 256, 36, 330), (3, 64, 50, 330),
-                                         (2, 40, 40, 500), (4, 256, 70, 330), (2, 41, 40, 500), (2, 203, 44, 330)])
-def test_deep_halo_bands(world, D, H, W):
+@pytest.mark.parametrize("world,D,H,W,dtype", [(3, 64, 60, 330, "f32"), (2, 128, 41, 420, "f32"), (2, 256, 36, 330, "f32"),
+                                               (3, 64, 50, 330, "f32"), (2, 40, 40, 500, "f32"), (4, 256, 70, 330, "f32"),
+                                               (2, 41, 40, 500, "f32"), (2, 203, 44, 330, "f32"),
+                                               (2, 256, 36, 200, "f64"), (3, 40, 60, 300, "f64"), (2, 130, 40, 200, "f64")])
+def test_deep_halo_bands(world, D, H, W, dtype):
     """DS_BAND_HALO=deep: bands of 16 rows or more keep four rows of each neighbour and exchange once
     per two-iteration step.  Same bar: every band's potentials, energy, labels, cost and crossing-out
     masks equal to the unpartitioned image's; every band has stepped by two (1 + 0 + 0 + 3 steps)."""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_gloo_worker, args=(world, _free_port(), "f32", D, H, W, out, "deep"), nprocs=world, join=True)
+    mp.spawn(_gloo_worker, args=(world, _free_port(), dtype, D, H, W, out, "deep"), nprocs=world, join=True)
     for rank in range(world):
         assert out[rank][:3] == (True, True, True), "rank %d: %s" % (rank, out[rank])
         assert out[rank][3] == 4, "rank %d ran %d two-iteration steps" % (rank, out[rank][3])
