@@ -379,7 +379,7 @@ const char *ds_comm_last_error(const ds_comm *c);
  *
  * Halo depth.  By default a band keeps one halo row per neighbour and a two-iteration step
  * exchanges one row four times, each exchange depending on the one before.  With
- * DS_BAND_HALO=deep in the environment at ds_create_band, an f32 band of 16 rows or more (with
+ * DS_BAND_HALO=deep in the environment at ds_create_band, a band of 16 rows or more (with
  * an interior for the two-iteration kernel, and 4 rows or more of image beyond it wherever it
  * has a neighbour) keeps FOUR rows of each neighbouring band: the two-iteration kernel then takes
  * every row of the band itself and a step needs ONE grouped exchange (four rows of the second
