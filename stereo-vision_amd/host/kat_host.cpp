@@ -164,6 +164,7 @@ int main()
                 DiffusionGraph::initialize(Img{{0, 0}}, Img{{0, 0}}, 2, 1.), on_device);
             const std::vector<double> array = create_array_of_epsilons(c, 0.01);
             CHECK(epsilon_search(c, array) == 0.);
+            if (on_device) CHECK(epsilon_search_streamed(c) == 0.);   // the same search without the array
         }
         {   // :131-145 (test_epsilon_search)
             CrossingOutGraph c = CrossingOutGraph::initialize(
@@ -183,6 +184,8 @@ int main()
             CHECK(array.size() == 3 && array[0] == 0. && close(array[1], 1.4, 1e-6) && close(array[2], 1.4, 1e-6));
             array = create_array_of_epsilons(c, 1.5);
             CHECK(array.size() == 2 && array[0] == 0. && close(array[1], 1.4, 1e-6));
+            // over that graph's own array (tolerance 0) both searches agree
+            if (on_device) CHECK(epsilon_search_streamed(c) == epsilon_search(c, create_array_of_epsilons(c, 0.)));
         }
     }
     {   // utils.rs:250-268 (dedup_f64)
