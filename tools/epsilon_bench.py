@@ -1,6 +1,6 @@
 """Developer tool: time of ds_epsilon_gaps (gaps of every vertex and edge, device sort, exact
-duplicates removed) next to the oracle's create_array_of_epsilons on the same potentials.
-env SIZES = "H,W,D;..." (the oracle only runs for the sizes listed in ORACLE_SIZES)."""
+duplicates removed). env SIZES = "H,W,D;...". That the values equal the CPU restatement's is a test
+(tests/test_gpu_epsilon.py), not this tool's business."""
 import os
 import sys
 import time
@@ -12,11 +12,9 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 load_package()
-from oracle import pyoracle  # noqa: E402
 from stereo_vision_amd import diffstereo, synth  # noqa: E402
 
 sizes = os.environ.get("SIZES", "48,64,40;100,100,40;200,200,40;400,400,40")
-oracle_sizes = os.environ.get("ORACLE_SIZES", "48,64,40")
 for spec in sizes.split(";"):
     H, W, D = (int(x) for x in spec.split(","))
     left, right, _ = synth.synthetic_pair(H, W, D)
@@ -29,13 +27,5 @@ for spec in sizes.split(";"):
     t_dev = time.perf_counter() - t0
     n_all = H * W * D * (1 + 4 * D)
     line = "%dx%dx%d: %.3f s on the GPU for %.3g slots -> %d distinct gaps" % (W, H, D, t_dev, n_all, len(gaps))
-    if spec in oracle_sizes.split(";"):
-        o = pyoracle.OracleGraph(left.astype(np.uint32), right.astype(np.uint32), D, 1.2)
-        o.set_potentials(np.asarray(g.get_phi(), dtype=np.float64))
-        t0 = time.perf_counter()
-        want = np.unique(o.create_array_of_epsilons(0.0))
-        t_cpu = time.perf_counter() - t0
-        line += "; oracle (1 core, incl. copying the array to numpy) %.2f s, same values: %s" % (
-            t_cpu, np.array_equal(gaps, want))
     print(line, flush=True)
     g.close()
