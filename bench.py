@@ -452,7 +452,7 @@ def main():
                              "value": valid_pairs(H, W, D) * args.sustained_steps / dt / 1e9, "seconds": dt}
     graph.close()
     if companions and dtype == "f32" and (args.workload + "_f64") in WORKLOADS:
-        # the same workload in the reference's own precision (one iteration per launch)
+        # the same workload in the reference's own precision
         g64 = diffstereo.DiffusionGraph(left, right, D, lam, dtype="f64")
         dt, _ = timed(SingleGpu(g64), g64, args.steps, args.warmup)
         _, _, roof64 = kernel_account(g64, args.steps, "f64", D, H, W, args.workload + "_f64", 1)
