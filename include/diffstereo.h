@@ -213,7 +213,11 @@ int ds_crossing_out(ds_handle *h, double epsilon, int max_passes, uint32_t *labe
  * epsilon search), where ds_crossing_out may fall on the other side of a threshold.  Price:
  * O(D^2) per pixel looked at instead of O(D) (1920 x 1080 x 128: 0.1 s for a pass over every
  * pixel; later passes look only at pixels with a neighbour whose mask has changed), and H*W*5
- * doubles + 2*H*W ints.  Whole-image handles.  ds_find_best_labeling may follow. */
+ * doubles + 2*H*W ints.  Whole-image handles.  ds_find_best_labeling may follow.
+ * An empty result (*not_empty = 0): with alive_out the passes go on to the reference's fixed
+ * point, where vertices kept by such a copy may still stand, and alive_out / labels hold them;
+ * without alive_out the call returns as soon as a pixel has lost every label, with every label
+ * 0xffffffff (the verdict is the same, and the search for epsilon asks thousands of times). */
 int ds_crossing_out_exact(ds_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
                           int *not_empty, int *passes);
 

@@ -2355,15 +2355,14 @@ static int crossing_out_exact(ds_handle *h, double epsilon, const double *mins, 
     int shift = 0;
     while ((1 << shift) < g.D) ++shift;
     const size_t lds = (size_t)g.D * (8 * sizeof(double) + sizeof(int) + 5) + 8;
-    // per pixel: in how many passes it lost labels, and the sum of its neighbours' counts when it was
-    // last looked at (co_exact_kernel looks at a pixel again only when the two differ)
+    // per pixel: the last pass in which it lost labels and the last pass in which it was looked at
+    // (co_exact_kernel looks at a pixel again only if a neighbour lost labels in that pass or later)
     const size_t pixels = (size_t)g.H * g.W;
     if (!h->co_version) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->co_version), 2 * pixels * sizeof(int));
         if (e != hipSuccess) return fail_hip(h, "hipMalloc (crossing-out versions)", e);
     }
-    HIPCHK(h, hipMemsetAsync(h->co_version, 0, pixels * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->co_version + pixels, 0xff, pixels * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->co_version, 0, 2 * pixels * sizeof(int), h->stream));
     const char *dirty_env = std::getenv("DS_CO_DIRTY");
     int *version = dirty_env && std::strcmp(dirty_env, "off") == 0 ? nullptr : h->co_version;
     int *seen = version ? version + pixels : nullptr;
@@ -2379,19 +2378,24 @@ static int crossing_out_exact(ds_handle *h, double epsilon, const double *mins, 
         if (h->dtype == DS_F64)
             hipLaunchKernelGGL(ds::co_exact_kernel<double>, grid, block, lds, h->stream, g, static_cast<const double *>(h->phi),
                                h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase, dirty_prev,
-                               dirty_cur, h->seg_pixels, h->grid_x, version, seen, per_block);
+                               dirty_cur, h->seg_pixels, h->grid_x, version, seen, per_block, passes_done);
         else
             hipLaunchKernelGGL(ds::co_exact_kernel<float>, grid, block, lds, h->stream, g, static_cast<const float *>(h->phi),
                                h->cost_px, h->lambda, epsilon, shift, mins, h->co_alive, h->co_flags, phase, dirty_prev,
-                               dirty_cur, h->seg_pixels, h->grid_x, version, seen, per_block);
+                               dirty_cur, h->seg_pixels, h->grid_x, version, seen, per_block, passes_done);
         HIPCHK(h, hipGetLastError());
         return DS_OK;
     };
     rc = launch(0);
     if (rc != DS_OK) return rc;
     h->co_begun = true;
+    // A pixel that has lost every label settles the verdict, and a caller that wants no masks stops
+    // there.  The masks of an empty result are something else: the reference relaxes on to its fixed
+    // point, where -- an edge copy whose twin was never set outlives the twin's vertex -- some
+    // vertices may still stand.  A caller that asks for the masks gets those.
+    const bool to_fixed_point = alive_out != nullptr;
     int done = 0, changed = 1, lost = 0;
-    while (done < max_passes && changed && !lost) {
+    while (done < max_passes && changed && !(lost && !to_fixed_point)) {
         HIPCHK(h, hipMemsetAsync(h->co_flags, 0, 2 * sizeof(int), h->stream));
         rc = launch(1);
         if (rc != DS_OK) return rc;
@@ -2399,12 +2403,14 @@ static int crossing_out_exact(ds_handle *h, double epsilon, const double *mins, 
         HIPCHK(h, hipMemcpyAsync(host_flags, h->co_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         changed = host_flags[0];
-        lost = host_flags[1];
+        lost |= host_flags[1];
         ++done;
     }
-    h->co_fixed = !changed || lost;
-    if (changed && !lost) return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
-    rc = ds_co_finish(h, lost, labels, alive_out, not_empty);
+    const bool stopped_early = lost && !to_fixed_point;
+    h->co_fixed = !changed || stopped_early;
+    if (changed && !stopped_early)
+        return fail(h, DS_ERR_STATE, "crossing out did not reach its fixed point within max_passes");
+    rc = ds_co_finish(h, stopped_early, labels, alive_out, not_empty);
     if (rc != DS_OK) return rc;
     if (passes) *passes = done;
     return DS_OK;

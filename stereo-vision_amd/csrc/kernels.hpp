@@ -1592,12 +1592,12 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
                                                           int shift, const double *__restrict__ mins, uint8_t *alive,
                                                           int *__restrict__ changed, int phase,
                                                           const uint8_t *dirty_prev, uint8_t *dirty_cur, int seg_pixels,
-                                                          int nseg, int *version, int *seen, int segs_per_block)
+                                                          int nseg, int *version, int *seen, int segs_per_block,
+                                                          int pass_no)
 {
     extern __shared__ double eps_lds[];
     __shared__ int holders, pixel_died;
     __shared__ unsigned long long due_lds, due_segments_lds;
-    __shared__ int sum_lds[64];
     const int D = g.D;
     double *own = eps_lds;            // [4][D]
     double *nbr = own + 4 * D;        // [4][D]: the neighbour's reverse slot
@@ -1635,9 +1635,13 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
     const long long flag_at = (long long)blockIdx.y * nseg + seg;
     bool block_changed = false;
     __syncthreads();  // the previous segment's shared words are done with
-    // Which of the segment's pixels are due: version[pixel] counts the passes in which the pixel lost
-    // labels, seen[pixel] is the sum of its neighbours' versions when it was last looked at; equal
-    // sums mean that no neighbour's mask has changed since, and neither can the pixel's answer.
+    // Which of the segment's pixels are due: version[pixel] is the last pass in which the pixel lost
+    // labels (0: none since the masks were made), seen[pixel] the last pass in which it was looked at.
+    // A pixel is due if a neighbour lost labels in that pass or later.  "Or later" would do if a
+    // visit were sure to see what its neighbours delete in the same pass, but it is not: another
+    // block's stores become visible to this one in no particular order before the kernel ends, its
+    // pass number possibly before its mask bytes.  Only what earlier launches wrote is relied on, so a
+    // pixel next to a deletion is looked at once more in the pass after it.
     // One lane per pixel looks that up (segments of up to 64 pixels; larger ones look at every pixel).
     const bool tracked = phase == 1 && version && 2 * seg_pixels <= 64;
     unsigned long long due = ~0ull;
@@ -1645,18 +1649,17 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
         if (tid < 64) {
             const int colour = tid / seg_pixels, q = tid % seg_pixels;
             const int j = 2 * (seg * seg_pixels + q) + ((i + colour) & 1);
-            int sum = 0;
             bool mine_due = false;
             if (tid < 2 * seg_pixels && j < g.W) {
                 const volatile int *v = version;
                 const long long pix = (long long)i * g.W + j;
-                if (j > 0) sum += v[pix - 1];
-                if (i > 0) sum += v[pix - g.W];
-                if (j + 1 < g.W) sum += v[pix + 1];
-                if (i + 1 < g.H) sum += v[pix + g.W];
-                mine_due = sum != seen[pix];
+                int latest = -1;
+                if (j > 0) latest = max(latest, v[pix - 1]);
+                if (i > 0) latest = max(latest, v[pix - g.W]);
+                if (j + 1 < g.W) latest = max(latest, v[pix + 1]);
+                if (i + 1 < g.H) latest = max(latest, v[pix + g.W]);
+                mine_due = latest >= seen[pix];
             }
-            sum_lds[tid] = sum;
             const unsigned long long ballot = __ballot(mine_due);
             if (tid == 0) due_lds = ballot;
         }
@@ -1665,7 +1668,7 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
         if (due == 0ull) continue;
     }
 
-    auto pixel = [&](int j, int slot) {
+    auto pixel = [&](int j) {
         const long long pix = (long long)i * g.W + j;
         const int colour = (i + j) & 1, jc = j >> 1, il = i - g.row0 + 1;
         const bool has[4] = {j > 0, i > 0, j + 1 < g.W, i + 1 < g.H};
@@ -1762,10 +1765,8 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
         if (tid == 0) {
             if (holders == 0) atomicOr(changed + 1, 1);
             if (tracked) {
-                // the sum was read before the masks were: a neighbour that changed in between makes
-                // the pixel due once more than needed, never once less
-                seen[pix] = sum_lds[slot];
-                if (pixel_died) version[pix] = version[pix] + 1;
+                seen[pix] = pass_no;
+                if (pixel_died) version[pix] = pass_no;
             }
         }
     };
@@ -1775,7 +1776,7 @@ __global__ __launch_bounds__(kBlock) void co_exact_kernel(Geometry g, const T *_
             const int slot = colour * seg_pixels + q;
             if (tracked && !((due >> slot) & 1ull)) continue;
             const int j = 2 * (seg * seg_pixels + q) + ((i + colour) & 1);
-            if (j < g.W) pixel(j, slot);  // uniform over the block
+            if (j < g.W) pixel(j);  // uniform over the block
         }
     if (block_changed && lane == 0) {
         atomicOr(changed, 1);

@@ -30,7 +30,6 @@ def worker(rank, world, port, budget, seed, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    rng = np.random.default_rng(seed)
     t0, case, bad, refusals = time.time(), 0, 0, 0
     try:
         while True:
@@ -40,6 +39,7 @@ def worker(rank, world, port, budget, seed, out):
             if not go.item():
                 break
             case += 1
+            rng = np.random.default_rng([seed, case])   # a case can be drawn again from its number alone
             H = int(rng.integers(world, 30 * world))
             W = int(rng.choice([rng.integers(2, 60), rng.integers(60, 350), rng.integers(350, 800)]))
             D = int(rng.choice([rng.integers(1, 257), rng.choice([1, 3, 4, 40, 64, 65, 128, 255, 256])]))

@@ -201,6 +201,34 @@ def test_exact_comparisons_at_every_gap_of_the_graph(H, W, D, dtype, iters):
     g.close()
 
 
+def test_exact_masks_of_an_empty_result_are_the_references():
+    """An empty result with masks asked for: the passes go on to the reference's fixed point, where
+    vertices held by an edge copy whose twin was never set may still stand (this graph has some at
+    three of its gaps; found by tests/fuzz_crossing_out.py).  Without masks the call stops at the
+    first pixel that lost every label: same verdict, every label 0xffffffff."""
+    H, W, D = 1, 10, 22
+    left, right = random_pair(H, W, seed=546)
+    g = diffstereo.DiffusionGraph(left, right, D, 1.2, dtype="f64")
+    g.iterate(3)
+    o = OracleGraph(left, right, D, 1.2, dtype="f64")
+    o.set_potentials(np.asarray(g.get_phi(), dtype=np.float64))
+    o.co_alloc(True)
+    standing = 0
+    for eps in g.epsilon_gaps():
+        o.initialize_with_epsilon(float(eps))
+        o.crossing_out()
+        got = g.crossing_out(float(eps), with_mask=True, exact=True)
+        assert np.array_equal(got["alive"], o.vertices), eps
+        assert got["not_empty"] == o.is_not_empty(), eps
+        quick = g.crossing_out(float(eps), exact=True)
+        assert quick["not_empty"] == got["not_empty"]
+        if not got["not_empty"]:
+            standing += int(got["alive"].any())
+            assert (quick["labels"] == 0xffffffff).all()
+    assert standing >= 3
+    g.close()
+
+
 def test_exact_crossing_out_leaves_the_state_other_entry_points_expect():
     left, right = random_pair(6, 9, seed=4)
     g = diffstereo.DiffusionGraph(left, right, 5, 1.2, dtype="f64")
