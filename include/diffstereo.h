@@ -178,6 +178,10 @@ int ds_energy_static(ds_handle *h, double *result_dev);
  * (diffusion_graph.rs:376-390,456-470): argmin_d f_t(d), first minimum wins.
  * mode 0 takes the same argmin of f_t as it stands after the pixel's vertex step
  * (diffusion_graph.rs:302-317), i.e. of q_t(d) + sum_n min_d' (lambda|d-d'| + phi_t'n'(d')).
+ * The inner minima are evaluated as the sweep evaluates them (prefix / suffix minima), not label
+ * pair by label pair: where two labels tie in exact arithmetic -- neighbouring labels of equal
+ * cost on messages that rise and fall by lambda; about one pixel in 10 000 on random inputs --
+ * the two roundings may order them differently and mode 0 may return the other label of the tie.
  * out: [rows][W]. */
 int ds_labels(ds_handle *h, int mode, uint32_t *out);
 
