@@ -558,9 +558,13 @@ int ds_sp_labels(ds_sp_handle *h, uint32_t *out);
  * simple_best_labeling (superpixel_stereo/src/crossing_out_graph.rs:72-236,240-312,397-480) on
  * the current potentials.  Edge penalties are evaluated by brute force in f64 in the crate's
  * expression order, so vertices and edges fall on the side of the thresholds where the crate
- * puts them (on an f32 handle: for the f32 potentials converted to f64).  labels [H][W]
+ * puts them (on an f32 handle: for the f32 potentials converted to f64).  The crate keeps a copy
+ * of every edge at each end, priced with that end's weight, and clears a node's copy on the death
+ * of the neighbour's vertex only through the neighbour's copy (:161-236), so a copy whose twin
+ * was never set outlives that vertex: reproduced, also for weights that differ between the two
+ * ends (ds_sp_set_edge_perimeters; the crate's own are symmetric).  labels [H][W]
  * (0xffffffff at pixels of a node without labels), alive_out (optional) = the crate's `vertices`
- * [windows down][windows across][2][D]. */
+ * [windows down][windows across][2][D]; all zero when *not_empty = 0. */
 int ds_sp_crossing_out(ds_sp_handle *h, double epsilon, int max_passes, uint32_t *labels, uint8_t *alive_out,
                        int *not_empty, int *passes);
 

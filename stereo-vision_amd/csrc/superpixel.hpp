@@ -326,9 +326,16 @@ __global__ void sp_expand_kernel(SpGeometry g, const uint8_t *__restrict__ super
 // in the reference's expression order -- perimeter * smoothing * |d - n_d| + phi_t + phi_t'
 // (diffusion_graph.rs:168-172) -- so that the thresholds fall where the reference's do.
 //   init:  alive(t, d) = d <= K and f_t(d) <= min f_t + eps;  gmin(t, n) = min over existing (d, n_d)
-//   relax: alive(t, d) stays iff towards every existing neighbour some n_d is alive there with
-//          g(d, n_d) <= gmin(t, n) + eps.  Repeated until nothing changes: the greatest consistent
-//          sub-graph, whatever the order of deletions.
+//   relax: alive(t, d) stays iff towards every existing neighbour some n_d has
+//          g(d, n_d) <= gmin(t, n) + eps  and  (n_d alive there  or not  g'(n_d, d) <= gmin(t', n') + eps),
+//          g' being the same edge as the neighbour prices it: its own weight, its own order of
+//          additions, its own pair minimum.  The reference keeps a copy of every edge at each end
+//          and clears a node's copy on the death of the neighbour's vertex only through the
+//          neighbour's copy (crossing_out_graph.rs:161-236), so a copy whose twin was never set
+//          outlives that vertex.  With the crate's own weights (symmetric) the two copies differ by
+//          rounding at most; with weights set per node they differ outright.  The condition is
+//          monotone in the masks: repeated until nothing changes it reaches the reference's fixed
+//          point whatever the order of deletions.
 template <typename T> struct SpCoArgs {
     const T *phi;
     const T *cost;
@@ -355,16 +362,18 @@ __global__ __launch_bounds__(kBlock) void sp_co_kernel(SpGeometry g, SpCoArgs<T>
     double *psi = lds, *red = lds + 9 * g.Dpad;
     __shared__ int any_alive;
     bool has[9];
-    int Kn[9];
+    int Kn[9], twin[9];
     long long nnode[9];
     for (int n = 0; n < 9; ++n) {
         int ni, nj, ns, nrev;
         has[n] = sp_neighbour(g, si, sj, s, n, &ni, &nj, &ns, &nrev);
         Kn[n] = -1;
         nnode[n] = 0;
+        twin[n] = 0;
         if (has[n]) {
             const int nc = sp_colour(ni, nj, ns);
             nnode[n] = (long long)nc * g.colour_nodes + sp_index(g, ni, nj);
+            twin[n] = nrev;
             Kn[n] = a.Kt[nnode[n]];
             if (d < g.Dpad)
                 psi[n * g.Dpad + d] = d <= Kn[n] ? (double)a.phi[sp_plane(g, nc, nrev) + sp_index(g, ni, nj) * g.Dpad + d] : 0.;
@@ -419,9 +428,16 @@ __global__ __launch_bounds__(kBlock) void sp_co_kernel(SpGeometry g, SpCoArgs<T>
         for (int n = 0; n < 9 && keep; ++n) {
             if (!has[n]) continue;
             const double limit = a.gmin[node * 9 + n] + a.eps;
+            // the neighbour's copy of the edge: its weight, its order of additions, its pair minimum
+            const double twin_weight = a.perim[nnode[n] * 9 + twin[n]];
+            const double twin_limit = a.gmin[nnode[n] * 9 + twin[n]] + a.eps;
             bool found = false;
-            for (int nd = 0; nd <= Kn[n] && !found; ++nd)
-                found = a.alive[nnode[n] * g.Dpad + nd] && edge(n, nd) <= limit;
+            for (int nd = 0; nd <= Kn[n] && !found; ++nd) {
+                if (!(edge(n, nd) <= limit)) continue;
+                const double diff = (double)(d > nd ? d - nd : nd - d);
+                const bool twin_set = twin_weight * a.lambda * diff + psi[n * g.Dpad + nd] + own[n] <= twin_limit;
+                found = a.alive[nnode[n] * g.Dpad + nd] || !twin_set;
+            }
             keep = found;
         }
     if (valid && a.alive[node * g.Dpad + d] && !keep) {

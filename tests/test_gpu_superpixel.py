@@ -137,6 +137,39 @@ def test_depth_map_and_crossing_out(H, W, D, sh, sw):
     g.close()
 
 
+@pytest.mark.parametrize("H,W,D,sh,sw,seed", [(7, 9, 11, 2, 3, 24), (8, 27, 8, 5, 6, 21), (19, 13, 12, 5, 4, 41),
+                                              (17, 12, 13, 7, 3, 49), (5, 8, 8, 2, 2, 61)])
+def test_crossing_out_with_weights_that_differ_between_the_ends_of_an_edge(H, W, D, sh, sw, seed):
+    """The crate prices each end's copy of an edge with that end's weight; with weights set per node
+    the two copies differ outright and a copy whose twin was never set keeps its vertex alive
+    (crossing_out_graph.rs:161-236).  Shapes tests/fuzz_superpixel.py found the one-copy predicate
+    wrong on."""
+    rng = np.random.default_rng(seed)
+    left, right = pair(H, W, seed)
+    o = SuperpixelOracle(left, right, D, 1.2, sh, sw)
+    o.edge_perimeters[...] = rng.uniform(0., 3., size=o.edge_perimeters.shape)
+    phi0 = random_phi(o, "f64", seed=seed)
+    g = superpixel.SuperpixelGraph(left, right, D, 1.2, sh, sw, perimeters=False, dtype="f64")
+    g.set_edge_perimeters(o.edge_perimeters)
+    g.set_phi(phi0)
+    g.iterate(2, superpixel.FOUR_COLOURS)
+    o.potentials[...] = g.get_phi()
+    o.co_alloc(True)
+    verdicts = set()
+    for eps in list(np.geomspace(0.05, 60., 40)) + [1e4]:
+        o.initialize_with_epsilon(eps)
+        o.crossing_out()
+        want_ok = o.is_not_empty()
+        got = g.crossing_out(eps, with_mask=True)
+        assert got["not_empty"] == want_ok, eps
+        if want_ok:
+            assert np.array_equal(got["alive"], o.vertices), eps
+            assert np.array_equal(got["labels"], o.simple_best_labeling()), eps
+        verdicts.add(want_ok)
+    assert True in verdicts
+    g.close()
+
+
 def test_reference_working_point():
     """The crate's own setting (main.rs:38-74): a 400 x 400 pair, 5 x 5 windows, 40 disparities,
     smoothing 1.2, weights from calculate_edge_perimeters, f64.  Two iterations in the crate's
