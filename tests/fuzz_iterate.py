@@ -1,5 +1,6 @@
 """Random shapes through ds_iterate against the O(D) oracle, bit for bit (a script, not collected
-by pytest: `python3 tests/fuzz_iterate.py [seconds] [seed]` on a GPU box).
+by pytest: `python3 tests/fuzz_iterate.py [seconds] [seed] [large]` on a GPU box; `large`: images of 70-700 rows
+and 300-4000 columns instead of 1-69 and 1-999).
 
 Every case draws H, W, D, the precision, the launch shape (two iterations per launch / one /
 half-sweeps, by the library's own environment switches) and a sequence of call lengths, starts
@@ -27,6 +28,7 @@ SWITCHES = [{"DS_CACHE_RESIDENT": "fused"}, {"DS_CACHE_RESIDENT": "fused"}, {"DS
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
     t0, case, bad = time.time(), 0, []
     while time.time() - t0 < budget:
         case += 1
@@ -37,6 +39,13 @@ def main():
         dtype = "f64" if rng.random() < 0.4 else "f32"
         env = SWITCHES[int(rng.integers(0, len(SWITCHES)))]
         calls = [int(x) for x in rng.integers(1, 8, size=int(rng.integers(1, 5)))]
+        if large:   # many strips and row segments of unequal length; at most 1.5e8 (pixel, label) pairs
+            H, W = int(rng.integers(70, 700)), int(rng.integers(300, 4000))
+            while H * W * D > 150_000_000:
+                H, W = max(70, H * 2 // 3), max(300, W * 3 // 4)
+                if H == 70 and W == 300:
+                    break
+            calls = [int(x) for x in rng.integers(1, 6, size=int(rng.integers(1, 4)))]
         for k in ("DS_CACHE_RESIDENT", "DS_FUSED2", "DS_FUSED", "DS_STORE_FIRST", "DS_FUSED2_PARTIAL"):
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -58,7 +67,7 @@ def main():
         g.close()
         if not ok:
             bad.append((case, H, W, D, dtype, env, calls))
-        if case % 10 == 0 or not ok:
+        if case % 10 == 0 or not ok or large:
             print("case %d: %dx%dx%d %s %s calls %s two-iteration steps %d -> %s (%.0f s)"
                   % (case, H, W, D, dtype, env, calls, info["steps"], "ok" if ok else "MISMATCH", time.time() - t0),
                   flush=True)
