@@ -1,6 +1,7 @@
 """Random shapes through the library's band protocol, several ranks sharing one GPU over the
 host-memory transport, against the unpartitioned image, bit for bit (a script, not collected by
-pytest: `python3 tests/fuzz_bands.py [seconds per world size] [seed]` on a GPU box).
+pytest: `python3 tests/fuzz_bands.py [seconds per world size] [seed] [large]` on a GPU box; `large`:
+bands of 16-150 rows and 300-3900 columns).
 
 Every case draws H, W, D, the precision, the halo mode and a sequence of call lengths; all ranks
 draw the same case from the same seed.  Compared per band: phi after the calls, labels, energy,
@@ -18,7 +19,7 @@ from __graft_entry__ import load_package  # noqa: E402
 from tests.util import random_pair, random_phi  # noqa: E402
 
 
-def worker(rank, world, port, budget, seed, out):
+def worker(rank, world, port, budget, seed, large, out):
     import faulthandler
     faulthandler.dump_traceback_later(int(budget) + 150, exit=True, file=sys.stderr)  # a stuck rank ends itself
     os.environ["DS_CACHE_RESIDENT"] = "fused"
@@ -47,6 +48,10 @@ def worker(rank, world, port, budget, seed, out):
             halo = "deep" if rng.random() < 0.4 else "one-row"
             if halo == "deep" and rng.random() < 0.8:   # mostly shapes whose bands can have it
                 H, W = int(rng.integers(16 * world, 30 * world)), int(rng.integers(150, 800))
+            if large:   # many strips per band, row segments of unequal length; at most 6e7 (pixel, label) pairs
+                H, W = int(rng.integers(16 * world, 150 * world)), int(rng.integers(300, 3900))
+                while H * W * D > 60_000_000 and (H > 16 * world or W > 300):
+                    H, W = max(16 * world, H * 2 // 3), max(300, W * 3 // 4)
             calls = [int(x) for x in rng.integers(0, 8, size=int(rng.integers(1, 4)))]
             eps = float(rng.choice([0.5, 4.0, 40.0]))
             os.environ["DS_BAND_HALO"] = halo
@@ -95,7 +100,7 @@ def worker(rank, world, port, budget, seed, out):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if not flag.item():
                 bad += 1
-            if rank == 0 and (case % 10 == 0 or not flag.item()):
+            if rank == 0 and (case % 10 == 0 or large or not flag.item()):
                 print("world %d case %d: %dx%dx%d %s halo %s calls %s (rank 0: %d two-iteration steps) -> %s (%.0f s)"
                       % (world, case, H, W, D, dtype, halo, calls, steps, "ok" if flag.item() else "MISMATCH",
                          time.time() - t0), flush=True)
@@ -108,13 +113,14 @@ def main():
     import torch.multiprocessing as mp
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
     total_bad = 0
     for world in (2, 3, 4):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         out = mp.Manager().dict()
-        mp.spawn(worker, args=(world, port, budget, seed + world, out), nprocs=world, join=True)
+        mp.spawn(worker, args=(world, port, budget, seed + world, large, out), nprocs=world, join=True)
         print("world %d: %d cases, %d mismatches (%d cases asked for a deep halo their bands cannot have and were "
               "refused on every rank)" % (world, out[0][0], out[0][1], out[0][2]), flush=True)
         total_bad += out[0][1]
