@@ -48,6 +48,10 @@ def main():
         ok = g.crossing_out(star, exact=True)["not_empty"]
         if not ok:
             print("case %d: the graph at the smallest epsilon %r is empty" % (case, star), flush=True)
+        again = g.epsilon_search(exact=True)
+        if again != star:
+            print("case %d: the search found %r, then %r" % (case, star, again), flush=True)
+            ok = False
         eps_list = [star, star * 0.999, star * 1.3, float(rng.uniform(0.0, 2.0 * star + 1e-3))]
         o = None
         if small:
